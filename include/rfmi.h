@@ -1,0 +1,225 @@
+/* rfmi.h -- C ABI of librfmi.so, the MI355X (gfx950) RoseTTAFold forward-path kernels.
+ *
+ * The reference (dohlee/rosettafold-pytorch) has no FFI / plugin interface: its only boundary
+ * is the Python nn.Module call surface.  This header is the boundary the
+ * build adds underneath that surface: one `extern "C"` entry point per op group of the
+ * forward path, each citing the reference lines whose arithmetic it replaces.  The Python
+ * host (rosettafold-pytorch_amd/) binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer; the caller allocates every output and workspace;
+ *   - kernels are launched on `stream` (a hipStream_t passed as void*), never allocate,
+ *     never synchronise, keep no global state: re-entrant;
+ *   - return value: 0 = launched; >0 = hipError_t from the launch; <0 = argument rejected
+ *     (RF_EINVAL...) and nothing was launched;
+ *   - dtype codes: RF_F32 = 0, RF_BF16 = 1.  "T" below = activation dtype chosen by the caller.
+ */
+#ifndef RFMI_H
+#define RFMI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RF_F32 0
+#define RF_BF16 1
+
+#define RF_EINVAL (-1)   /* inconsistent sizes / unsupported combination */
+#define RF_EALIGN (-2)   /* pointer or stride not aligned as the kernel needs */
+
+#define RF_ACT_NONE 0
+#define RF_ACT_RELU 1
+#define RF_ACT_ELU 2
+#define RF_ACT_RELU_EPS 3 /* relu(x)+eps for column < act_nvalid (row < -act_nvalid if negative), 0 beyond (FAVOR+ ReLU features) */
+#define RF_ACT_LEAKY 4    /* LeakyReLU(0.01), rf_layernorm only */
+
+#define RF_BIAS_NONE 0
+#define RF_BIAS_COL 1 /* bias[n] */
+#define RF_BIAS_ROW 2 /* bias[m] */
+
+#define RF_AMODE_PLAIN 0
+#define RF_AMODE_CONV3X3 1 /* A rows are NHWC pixels, K = 9*C im2col on the fly */
+
+/* Strided / batched / chunked GEMM:  C[z][m][n] = epilogue( alpha * sum_k A[z][m][k] * B[z][n][k] ).
+ * Both operands are K-contiguous ("TN"); every contraction of the forward path is phrased
+ * this way (nn.Linear rf.py:195-281, the einsums rf.py:254,257,424,592,916, conv2d rf.py:452-457,
+ * resnet.py:19-38).  Element offsets (in elements of the operand dtype):
+ *   batch z = (z0*nb1 + z1)*nb2 + z2
+ *   A(z,m,k) = z0*a_bs[0]+z1*a_bs[1]+z2*a_bs[2] + (m / a_rc)*a_ro + (m % a_rc)*a_ri + (k / kc)*a_ko + (k % kc)
+ *   B(z,n,k) = likewise with b_*            (kc = K for a plain contiguous K)
+ *   C(z,m,n) = z.c_bs + (m / c_rc)*c_ro + (m % c_rc)*c_ri + (n / c_cc)*c_co + (n % c_cc)
+ * a_rc/b_rc/c_rc/c_cc <= 0 mean "no split" (offset = m*..ri, n).
+ * RF_AMODE_CONV3X3: A is NHWC [conv_n, conv_h, conv_w, conv_c], m = pixel index, k = tap*C + c
+ * (tap = 3*(di+1)+(dj+1)), zero padding, dilation conv_dil; a_* strides are ignored.
+ */
+typedef struct rf_gemm_desc {
+  int32_t M, N, K;
+  int32_t nb0, nb1, nb2;
+  int32_t ab_dtype;  /* RF_BF16 (MFMA path) or RF_F32 (exact f32 path) */
+  int32_t c_dtype;   /* RF_BF16 or RF_F32 */
+  int32_t kc;
+  int32_t a_mode;
+  int32_t a_rc, b_rc, c_rc, c_cc;
+  int64_t a_bs[3], a_ro, a_ri, a_ko;
+  int64_t b_bs[3], b_ro, b_ri, b_ko;
+  int64_t c_bs[3], c_ro, c_ri, c_co;
+  int32_t conv_n, conv_h, conv_w, conv_c, conv_dil;
+  int32_t bias_mode;
+  int32_t act;
+  int32_t act_nvalid;
+  float act_eps;
+  float alpha;
+  int32_t tile_cfg;  /* 0 = auto; else index into the tile table (tuning/tests) */
+  const void* A;
+  const void* B;
+  void* C;
+  const float* bias;     /* fp32 */
+  const float* residual; /* fp32, same layout as C; C = residual + epilogue(...) ; may alias C */
+} rf_gemm_desc;
+
+int rf_gemm(const rf_gemm_desc* d, void* stream);
+
+/* LayerNorm over the last dim (nn.LayerNorm, rf.py:323,328,416,435,437,442,443,565,573,580,672,
+ * 685,686,758,759,765,771,876,877,883,886,1136; ea/modules.py:553).  rows x D, fp32 statistics. */
+int rf_layernorm(const void* x, int x_dtype, int64_t x_ld, void* y, int y_dtype, int64_t y_ld, int64_t rows,
+                 int D, const float* gamma, const float* beta, float eps, int groups, int act, void* stream);
+/* groups > 1: row r uses gamma/beta[(r % groups)*D ..] (the 8 radial MLPs of one SE(3) layer normalised in one
+ * launch, ea/modules.py:265-275); act: RF_ACT_NONE | RF_ACT_RELU | RF_ACT_LEAKY applied after the affine. */
+
+/* y[r, :] = 0.5*(x[b,i,j,:] + x[b,j,i,:]) normalised WITHOUT affine (shared front of the four
+ * MsaUpdateWithPairLayer.pair2att of a block: Symmetrization + LayerNorm, rf.py:550-566). */
+int rf_sym_layernorm(const float* pair, void* y, int y_dtype, int B, int L, int D, float eps, void* stream);
+
+/* Row softmax with strides: for r in [0,rows): y[r*y_rs + c] = softmax_c(scale * x[r*x_rs + c*x_cs]).
+ * (rf.py:215,255,569,657,914). */
+int rf_softmax(const float* x, int64_t x_rs, int64_t x_cs, void* y, int y_dtype, int64_t y_rs, int64_t rows,
+               int cols, float scale, void* stream);
+
+/* Tied-attention softmax (rf.py:255,261-265): logits fp32 [B,H,L,L] -> att T [B,H,L,L] and, when
+ * att_sym != NULL, the symmetrised map 0.5*(att+att^T) as fp32 [B,L,L,H] (written with ld sym_ld). */
+int rf_tied_softmax(const float* logits, void* att, int att_dtype, float* att_sym, int64_t sym_ld, int B, int H,
+                    int L, void* stream);
+
+/* PositionWiseWeightFactor core (rf.py:205-217): w[b,n,h,l] = softmax_n( sum_d q0[b,l,h,d]*k[b,n,l,h,d] ) with
+ * q0 already scaled by the caller's projection (the d_head^-0.5 factor is `scale`).
+ * q0: T [B,L,H*dh] (ld q0_ld); k: T [B,N,L,*] rows of ld k_ld, head h at column k_col0 + h*dh.
+ * w (fp32 [B,N,H,L]) may be NULL.  When q_scale != NULL the kernel also does the fused
+ * `q = q * w * qscale` of rf.py:252 in place on q_scale: T [B,N,L,*] (ld qs_ld, column qs_col0 + h*dh). */
+int rf_poswise(const void* q0, int64_t q0_ld, const void* k, int64_t k_ld, int k_col0, float* w, void* q_scale,
+               int64_t qs_ld, int qs_col0, int dtype, int B, int N, int L, int H, int dh, float scale, float qscale,
+               void* stream);
+
+/* y[b,l,:] = sum_n w[b,n,0,l] * x[b,n,l,:]   (rf.py:723, rf.py:797); x T [B,N,L,D], y fp32 [B,L,D] (ld y_ld) */
+int rf_weighted_msa_sum(const void* x, int dtype, const float* w, float* y, int64_t y_ld, int B, int N, int L, int D,
+                        void* stream);
+
+/* InstanceNorm2d(affine, eps) on NHWC (rf.py:453,457; resnet.py:29,39,63) in two steps:
+ * stats: sums[b,c,0..1] += (sum, sumsq) over the L*L pixels (sums must be zeroed by the caller);
+ * apply: y = act( (x-mean)*rstd*gamma + beta [+ residual] ) ; act = RF_ACT_NONE | RF_ACT_ELU. */
+int rf_instnorm_stats(const void* x, int x_dtype, void* sums /* 2*B*C doubles */, int B, int64_t HW, int C, void* stream);
+int rf_instnorm_apply(const void* x, int x_dtype, const void* sums, const float* gamma, const float* beta, float eps,
+                      const float* residual, int act, void* y, int y_dtype, void* y2, int y2_dtype, int B, int64_t HW,
+                      int C, void* stream);
+
+/* MsaEmbedding (rf.py:106-120): y[b,n,l,:] = emb[msa[b,n,l]] + pe[aa_idx[b,l]] + qenc[n==0 ? 0 : 1]; fp32 out. */
+int rf_msa_embed(const int64_t* msa, const int64_t* aa_idx, const float* emb, const float* pe, const float* qenc,
+                 float* y, int B, int N, int L, int D, void* stream);
+
+/* PairEmbedding (rf.py:123-181, 79-103) with the 289->d Linear factorised into two 21-row tables:
+ * y[b,i,j,:] = tl[seq[b,j]] + tr[seq[b,i]] + wsep*log(|idx_i-idx_j|+1) + bias + [pe[idx_i] | pe[idx_j]]. */
+int rf_pair_embed(const int64_t* seq, const int64_t* aa_idx, const float* tl, const float* tr, const float* wsep,
+                  const float* bias, const float* pe, float* y, int B, int L, int D, void* stream);
+
+/* Generic strided copy / cast / transpose (einops rearrange of the reference, e.g. rf.py:258,403,408,593):
+ * y[i0,i1,i2,i3] = x[...] over a 4-D index space with element strides per side. */
+int rf_copy4d(const void* x, int x_dtype, const int64_t xs[4], void* y, int y_dtype, const int64_t ys[4],
+              const int64_t dims[4], void* stream);
+
+/* y = a*x + b*z  elementwise fp32/T (n elements; z may be NULL) */
+int rf_axpby(const void* x, int x_dtype, float a, const void* z, int z_dtype, float b, void* y, int y_dtype,
+             int64_t n, void* stream);
+
+/* FAVOR+ softmax-kernel features (performer-pytorch softmax_kernel as called at rf.py:313-318; third party,
+ * parity unpinned).  One workgroup per (sequence, head) S.  dash = (d^-1/4 x) P^T from rf_gemm, T, laid out
+ * [S][n][m_pad] (transposed=0) or [S][m_pad][n] (transposed=1).  Row r of S in x (T) starts at
+ * s0*xs[0]+s1*xs[1]+s2*xs[2]+r*xs[3] with S = (s0*n1+s1)*n2+s2.
+ * y = m^-1/2 * (exp(dash - |x|^2 d^-1/2 /2 - max) + eps) for features < m, 0 for the padded ones.
+ * is_query: max over the feature axis per row; else over (n, m) per S.  y may alias dash. */
+int rf_favor_softmax_features(const void* dash, const void* x, const int64_t xs[4], int n1, int n2, void* y, int dtype,
+                              int64_t S, int n, int m, int m_pad, int dh, int is_query, int transposed, float eps,
+                              void* stream);
+
+/* Linear-attention normalisation (performer-pytorch linear_attention): y[r, :dh] = num[r, :dh] / num[r, dh]
+ * where column dh of `num` carries q'.ksum (the context matrix has a ones-row appended). */
+int rf_linattn_normalize(const float* num, int64_t num_ld, void* y, int y_dtype, int64_t y_ld, int64_t rows, int dh,
+                         void* stream);
+
+/* Outer-product features (rf.py:476-485): feat[b,i,j, c0 + (0..2p)] = msa1d[b,i,:], feat[.., c0+2p + (0..2p)] = msa1d[b,j,:] */
+int rf_tile_1d_feats(const float* msa1d, void* feat, int dtype, int64_t feat_ld, int c0, int B, int L, int P2,
+                     void* stream);
+
+/* GraphTransformer attention core (rf.py:647-662) for one layer: q,k,v T [B,L,H*d]; e T [B,L,L,H*d];
+ * out fp32 [B,L,H*d] = sum_j softmax_j(scale*(q.k_j + q.e_ij)) * (v_j + e_ij). */
+int rf_graph_attention(const void* q, const void* k, const void* v, const void* e, int dtype, float* out, int B, int L,
+                       int H, int d, float scale, void* stream);
+
+/* MsaUpdateWithPairAndCoord attention map (rf.py:899-914): att T [B,4,L,L] = softmax_j(q.k*1 + (dist<bin ? 0 : -1e9));
+ * q (pre-scaled by the caller) and k: fp32 [B,L,H*dq]; ca: fp32 xyz [B,L,3,3] (CA = atom 1). */
+int rf_dist_masked_attention(const float* q, const float* k, const float* xyz, const float* bins, void* att,
+                             int att_dtype, int B, int L, int H, int dq, void* stream);
+
+/* ---- SE(3) structure module (rf.py:752-862, se3_modules.py:83-171, ea/modules.py) -------------------------- */
+
+/* kNN graph (rf.py:823-862) in dense form: mask[b,i,j] = 1 iff edge i->j exists
+ * (j among the k nearest CA of i, ties broken by lower j, or |idx_i-idx_j| < kmin; self loops only when k >= L). */
+int rf_knn_mask(const float* xyz, const int64_t* aa_idx, uint8_t* mask, int B, int L, int k, int kmin, void* stream);
+
+/* Compact the dense mask into an edge list sorted by (b,i,j) (row-major torch.where order, rf.py:853):
+ * src/dst node ids (b*L+i / b*L+j), eid[b,i,j] = edge id or -1, count[0] = number of edges.
+ * At most min(L, k + 2*(kmin-1)) edges per row, so capacity B*L*min(L,k+2*kmin-2) suffices.
+ * row_ws: 2*B*L int32 scratch. */
+int rf_edges_from_mask(const uint8_t* mask, int32_t* src, int32_t* dst, int32_t* eid, int32_t* count, int32_t* row_ws,
+                       int B, int L, void* stream);
+
+/* Per-edge geometry (ea/modules.py:26-108): d = CA[dst]-CA[src]; r; real SH Y0..Y2 and the four equivariant
+ * bases folded with the Q_J constants: basis layout [E, 1+3+3+27] floats = (0,0)[1] (0,1)[3x1] (1,0)[1x3] (1,1)[3x3x3];
+ * also feat[e, :] = [w(edge embedding, d_edge) | r] with leading dim feat_ld. */
+int rf_se3_edge_geometry(const float* xyz, const float* edge_emb, const int32_t* src, const int32_t* dst,
+                         const int32_t* count, float* basis, float* feat, int64_t feat_ld, int L, int d_edge,
+                         int64_t capacity, void* stream);
+
+/* Partial convolution message (ea/modules.py:612-641 + 287-325): for output degree `dout` with `mo` channels,
+ * msg[e, o, a] = sum_{di} sum_{i,b,f} R_{di}[e, o, i, f] * basis_{di,dout}[e, a, b, f] * h_{di}[src[e], i, b].
+ * R0/R1: radial outputs (fp32, [E, mo*mi0*nf0] and [E, mo*mi1*nf1]); h0 [V, mi0], h1 [V, mi1, 3]. */
+int rf_se3_message(const float* R0, const float* R1, const float* basis, const float* h0, const float* h1,
+                   const int32_t* src, const int32_t* count, float* msg, int mo, int dout, int mi0, int mi1,
+                   int64_t capacity, void* stream);
+
+/* Graph attention (ea/modules.py:738-774): e = <k_edge, q[dst]>/sqrt(nfeat) per head, softmax over incoming edges
+ * of each dst node, out[dst] = sum a * v.  k/v per-edge: k0 [E,mk0] k1 [E,mk1,3] v0 [E,mv0] v1 [E,mv1,3]; q per node.
+ * One wave per (dst node, head) walks column dst of the dense eid map in fixed order (deterministic). */
+int rf_se3_attention(const float* k0, const float* k1, const float* q0, const float* q1, const float* v0,
+                     const float* v1, const int32_t* eid, float* out0, float* out1, int heads, int mk0, int mk1,
+                     int mv0, int mv1, int V, int L, void* stream);
+
+/* GNormBias (ea/modules.py:391-406): y = relu(|v| + b) * v/|v| per channel, v [V, m, 2d+1]. */
+int rf_se3_norm_bias(const float* v, const float* bias, float* y, int64_t V, int m, int deg, void* stream);
+
+/* GAttentiveSelfInt front (ea/modules.py:446-455): s[v, a*m+b] = sign-preserving clamp(<v_a, v_b>, 1e-12). */
+int rf_se3_gram(const float* v, float* s, int64_t V, int m, int deg, void* stream);
+/* GAttentiveSelfInt back (ea/modules.py:458-471): y[v,o,:] = sum_m softmax_m(att[v,o,m]) * x[v,m,:]. */
+int rf_se3_attn_apply(const float* att, const float* x, float* y, int64_t V, int m_out, int m_in, int deg,
+                      void* stream);
+
+/* Coordinate update (rf.py:816-819): xyz_out from xyz and displacement [B*L,3,3]. */
+int rf_coord_apply(const float* xyz, const float* disp, float* xyz_out, int64_t nres, void* stream);
+
+/* Library self-description */
+int rf_version(void);
+const char* rf_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFMI_H */

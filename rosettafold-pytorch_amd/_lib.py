@@ -1,0 +1,90 @@
+"""ctypes binding of librfmi.so (include/rfmi.h).  The product has NO fallback: if the HIP
+library is missing or a symbol is absent this module raises at import."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librfmi.so")
+
+RF_F32, RF_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_ELU, ACT_RELU_EPS, ACT_LEAKY = 0, 1, 2, 3, 4
+BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
+AMODE_PLAIN, AMODE_CONV3X3 = 0, 1
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    """struct rf_gemm_desc (include/rfmi.h)."""
+    _fields_ = [
+        ("M", i32), ("N", i32), ("K", i32),
+        ("nb0", i32), ("nb1", i32), ("nb2", i32),
+        ("ab_dtype", i32), ("c_dtype", i32), ("kc", i32), ("a_mode", i32),
+        ("a_rc", i32), ("b_rc", i32), ("c_rc", i32), ("c_cc", i32),
+        ("a_bs", i64 * 3), ("a_ro", i64), ("a_ri", i64), ("a_ko", i64),
+        ("b_bs", i64 * 3), ("b_ro", i64), ("b_ri", i64), ("b_ko", i64),
+        ("c_bs", i64 * 3), ("c_ro", i64), ("c_ri", i64), ("c_co", i64),
+        ("conv_n", i32), ("conv_h", i32), ("conv_w", i32), ("conv_c", i32), ("conv_dil", i32),
+        ("bias_mode", i32), ("act", i32), ("act_nvalid", i32),
+        ("act_eps", f32), ("alpha", f32), ("tile_cfg", i32),
+        ("A", vp), ("B", vp), ("C", vp), ("bias", vp), ("residual", vp),
+    ]
+
+
+I64x4 = i64 * 4
+
+# name -> argtypes (restype is always int unless noted); mirrors include/rfmi.h declaration order
+PROTOTYPES = {
+    "rf_gemm": [C.POINTER(GemmDesc), vp],
+    "rf_layernorm": [vp, i32, i64, vp, i32, i64, i64, i32, vp, vp, f32, i32, i32, vp],
+    "rf_sym_layernorm": [vp, vp, i32, i32, i32, i32, f32, vp],
+    "rf_softmax": [vp, i64, i64, vp, i32, i64, i64, i32, f32, vp],
+    "rf_tied_softmax": [vp, vp, i32, vp, i64, i32, i32, i32, vp],
+    "rf_poswise": [vp, i64, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp],
+    "rf_weighted_msa_sum": [vp, i32, vp, vp, i64, i32, i32, i32, i32, vp],
+    "rf_instnorm_stats": [vp, i32, vp, i32, i64, i32, vp],
+    "rf_instnorm_apply": [vp, i32, vp, vp, vp, f32, vp, i32, vp, i32, vp, i32, i32, i64, i32, vp],
+    "rf_msa_embed": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "rf_pair_embed": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "rf_copy4d": [vp, i32, C.POINTER(I64x4), vp, i32, C.POINTER(I64x4), C.POINTER(I64x4), vp],
+    "rf_axpby": [vp, i32, f32, vp, i32, f32, vp, i32, i64, vp],
+    "rf_favor_softmax_features": [vp, vp, C.POINTER(I64x4), i32, i32, vp, i32, i64, i32, i32, i32, i32, i32, i32, f32, vp],
+    "rf_linattn_normalize": [vp, i64, vp, i32, i64, i64, i32, vp],
+    "rf_tile_1d_feats": [vp, vp, i32, i64, i32, i32, i32, i32, vp],
+    "rf_graph_attention": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, f32, vp],
+    "rf_dist_masked_attention": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "rf_knn_mask": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "rf_edges_from_mask": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "rf_se3_edge_geometry": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, vp],
+    "rf_se3_message": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, vp],
+    "rf_se3_attention": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "rf_se3_norm_bias": [vp, vp, vp, i64, i32, i32, vp],
+    "rf_se3_gram": [vp, vp, i64, i32, i32, vp],
+    "rf_se3_attn_apply": [vp, vp, vp, i64, i32, i32, i32, vp],
+    "rf_coord_apply": [vp, vp, vp, i64, vp],
+    "rf_version": [],
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C rosettafold-pytorch_amd/csrc`).  There is no CPU / PyTorch fallback.")
+
+lib = C.CDLL(LIB_PATH)
+for _name, _args in PROTOTYPES.items():
+    _fn = getattr(lib, _name)  # AttributeError if the library does not export it
+    _fn.argtypes = _args
+    _fn.restype = C.c_int
+lib.rf_build_info.restype = C.c_char_p
+lib.rf_build_info.argtypes = []
+
+
+class RfmiError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "RF_EINVAL (inconsistent arguments)", -2: "RF_EALIGN (misaligned pointer/stride)"}.get(
+            rc, f"hipError_t {rc}")
+        raise RfmiError(f"{what} failed: {kind}")

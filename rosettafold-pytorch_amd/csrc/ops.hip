@@ -1,0 +1,621 @@
+// Normalisation, softmax, embedding and small-attention kernels of the RoseTTAFold forward path
+// (gfx950).  All of these are HBM-bandwidth / latency bound: one wave (64 lanes) per row where a
+// row reduction is needed, wave-shuffle reductions, fp32 statistics, dtype-generic (fp32 / bf16)
+// loads and stores.  Reference lines are cited per entry point in include/rfmi.h.
+#include "common.h"
+
+#define RF_CHECK_DT(dt) \
+  if ((dt) != RF_F32 && (dt) != RF_BF16) return RF_EINVAL
+
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+__device__ __forceinline__ float block_sum(float v, float* red) {  // 256 threads
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, the row lives in registers (NV values per lane)
+// ------------------------------------------------------------------------------------------------
+template <int NV, bool SYM>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int x_dt, int64_t x_ld, void* y, int y_dt,
+                                                        int64_t y_ld, int64_t rows, int D, const float* gamma,
+                                                        const float* beta, float eps, int L, int groups, int act) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  int64_t base = row * x_ld, base2 = 0;
+  if (SYM) {  // row = (b,i,j) of a [B,L,L,D] tensor; partner row (b,j,i)
+    const int64_t j = row % L, i = (row / L) % L, b = row / ((int64_t)L * L);
+    base2 = ((b * L + j) * L + i) * x_ld;
+  }
+  float v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < NV; ++t) {
+    const int c = lane + 64 * t;
+    float a = 0.f;
+    if (c < D) {
+      a = ld(x, x_dt, base + c);
+      if (SYM) a = 0.5f * (a + ld(x, x_dt, base2 + c));
+    }
+    v[t] = a;
+    s += a;
+  }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < NV; ++t) {
+    const int c = lane + 64 * t;
+    const float dlt = c < D ? v[t] - mean : 0.f;
+    q += dlt * dlt;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+  for (int t = 0; t < NV; ++t) {
+    const int c = lane + 64 * t;
+    if (c < D) {
+      float o = (v[t] - mean) * rstd;
+      if (gamma) {
+        const int64_t g = (groups > 1 ? (row % groups) * D : 0) + c;
+        o = o * gamma[g] + beta[g];
+      }
+      if (act == RF_ACT_RELU) o = fmaxf(o, 0.f);
+      if (act == RF_ACT_LEAKY) o = o > 0.f ? o : 0.01f * o;
+      st(y, y_dt, row * y_ld + c, o);
+    }
+  }
+}
+
+template <bool SYM>
+static int launch_ln(const void* x, int x_dt, int64_t x_ld, void* y, int y_dt, int64_t y_ld, int64_t rows, int D,
+                     const float* g, const float* b, float eps, int L, int groups, int act, hipStream_t s) {
+  if (rows <= 0 || D <= 0 || D > 2304) return RF_EINVAL;
+  const dim3 grid(cdiv(rows, 4)), blk(256);
+#define RF_LN(NV) hipLaunchKernelGGL((layernorm_kernel<NV, SYM>), grid, blk, 0, s, x, x_dt, x_ld, y, y_dt, y_ld, rows, D, g, b, eps, L, groups, act)
+  if (D <= 64) RF_LN(1);
+  else if (D <= 128) RF_LN(2);
+  else if (D <= 320) RF_LN(5);
+  else if (D <= 384) RF_LN(6);
+  else if (D <= 512) RF_LN(8);
+  else if (D <= 1024) RF_LN(16);
+  else RF_LN(36);
+#undef RF_LN
+  return rf_launch_status();
+}
+
+extern "C" int rf_layernorm(const void* x, int x_dtype, int64_t x_ld, void* y, int y_dtype, int64_t y_ld, int64_t rows,
+                            int D, const float* gamma, const float* beta, float eps, int groups, int act,
+                            void* stream) {
+  RF_CHECK_DT(x_dtype);
+  RF_CHECK_DT(y_dtype);
+  if ((gamma == nullptr) != (beta == nullptr)) return RF_EINVAL;
+  return launch_ln<false>(x, x_dtype, x_ld, y, y_dtype, y_ld, rows, D, gamma, beta, eps, 0, groups, act,
+                          (hipStream_t)stream);
+}
+
+extern "C" int rf_sym_layernorm(const float* pair, void* y, int y_dtype, int B, int L, int D, float eps, void* stream) {
+  RF_CHECK_DT(y_dtype);
+  return launch_ln<true>(pair, RF_F32, D, y, y_dtype, D, (int64_t)B * L * L, D, nullptr, nullptr, eps, L, 1, 0,
+                         (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// strided row softmax: one wave per row
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_kernel(const float* x, int64_t x_rs, int64_t x_cs, void* y, int y_dt,
+                                                      int64_t y_rs, int64_t rows, int cols, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * x_rs;
+  float mx = -INFINITY;
+  for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, xr[c * x_cs] * scale);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += __expf(xr[c * x_cs] * scale - mx);
+  const float inv = 1.f / wave_sum(s);
+  for (int c = lane; c < cols; c += 64) st(y, y_dt, row * y_rs + c, __expf(xr[c * x_cs] * scale - mx) * inv);
+}
+
+extern "C" int rf_softmax(const float* x, int64_t x_rs, int64_t x_cs, void* y, int y_dtype, int64_t y_rs, int64_t rows,
+                          int cols, float scale, void* stream) {
+  RF_CHECK_DT(y_dtype);
+  if (rows <= 0 || cols <= 0) return RF_EINVAL;
+  hipLaunchKernelGGL(softmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, x_rs, x_cs, y, y_dtype,
+                     y_rs, rows, cols, scale);
+  return rf_launch_status();
+}
+
+__global__ __launch_bounds__(256) void att_sym_kernel(const void* att, int dt, float* sym, int64_t sym_ld, int B, int H,
+                                                      int L) {
+  // sym[b,i,j,h] = 0.5*(att[b,h,i,j] + att[b,h,j,i])
+  const int64_t n = (int64_t)B * L * L * H;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int h = e % H;
+    const int64_t t = e / H;
+    const int j = t % L, i = (t / L) % L;
+    const int64_t b = t / ((int64_t)L * L);
+    const int64_t o = (b * H + h) * L;
+    sym[t * sym_ld + h] = 0.5f * (ld(att, dt, (o + i) * L + j) + ld(att, dt, (o + j) * L + i));
+  }
+}
+
+extern "C" int rf_tied_softmax(const float* logits, void* att, int att_dtype, float* att_sym, int64_t sym_ld, int B,
+                               int H, int L, void* stream) {
+  RF_CHECK_DT(att_dtype);
+  const int64_t rows = (int64_t)B * H * L;
+  hipLaunchKernelGGL(softmax_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, (int64_t)L,
+                     (int64_t)1, att, att_dtype, (int64_t)L, rows, L, 1.0f);
+  if (att_sym) {
+    const int64_t n = (int64_t)B * L * L * H;
+    hipLaunchKernelGGL(att_sym_kernel, dim3(min(cdiv(n, 256), 8192u)), dim3(256), 0, (hipStream_t)stream, att,
+                       att_dtype, att_sym, sym_ld, B, H, L);
+  }
+  return rf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// PositionWiseWeightFactor core: block per (b,l); thread per (n,h) dot product; softmax over n
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void poswise_kernel(const void* q0, int64_t q0_ld, const void* k, int64_t k_ld,
+                                                      int k_col0, float* w, void* qs, int64_t qs_ld, int qs_col0,
+                                                      int dt, int B, int N, int L, int H, int dh, float scale,
+                                                      float qscale) {
+  extern __shared__ float sm[];  // logits [H][N]
+  const int bl = blockIdx.x, b = bl / L, l = bl % L;
+  const int NH = N * H;
+  for (int e = threadIdx.x; e < NH; e += 256) {
+    const int n = e / H, h = e % H;
+    const int64_t kb = (((int64_t)b * N + n) * L + l) * k_ld + k_col0 + h * dh;
+    const int64_t qb = ((int64_t)b * L + l) * q0_ld + h * dh;
+    float a = 0.f;
+    for (int c = 0; c < dh; ++c) a = fmaf(ld(q0, dt, qb + c), ld(k, dt, kb + c), a);
+    sm[h * N + n] = a * scale;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int h = wv; h < H; h += 4) {
+    float mx = -INFINITY;
+    for (int n = lane; n < N; n += 64) mx = fmaxf(mx, sm[h * N + n]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int n = lane; n < N; n += 64) s += __expf(sm[h * N + n] - mx);
+    const float inv = 1.f / wave_sum(s);
+    for (int n = lane; n < N; n += 64) sm[h * N + n] = __expf(sm[h * N + n] - mx) * inv;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < NH; e += 256) {
+    const int n = e / H, h = e % H;
+    const float wv_ = sm[h * N + n];
+    if (w) w[(((int64_t)b * N + n) * H + h) * L + l] = wv_;
+    if (qs) {
+      const int64_t o = (((int64_t)b * N + n) * L + l) * qs_ld + qs_col0 + h * dh;
+      const float f = wv_ * qscale;
+      for (int c = 0; c < dh; ++c) st(qs, dt, o + c, ld(qs, dt, o + c) * f);
+    }
+  }
+}
+
+extern "C" int rf_poswise(const void* q0, int64_t q0_ld, const void* k, int64_t k_ld, int k_col0, float* w,
+                          void* q_scale, int64_t qs_ld, int qs_col0, int dtype, int B, int N, int L, int H, int dh,
+                          float scale, float qscale, void* stream) {
+  RF_CHECK_DT(dtype);
+  const size_t lds = (size_t)N * H * sizeof(float);
+  if (lds > 64 * 1024) return RF_EINVAL;
+  hipLaunchKernelGGL(poswise_kernel, dim3(B * L), dim3(256), lds, (hipStream_t)stream, q0, q0_ld, k, k_ld, k_col0, w,
+                     q_scale, qs_ld, qs_col0, dtype, B, N, L, H, dh, scale, qscale);
+  return rf_launch_status();
+}
+
+__global__ __launch_bounds__(256) void weighted_msa_sum_kernel(const void* x, int dt, const float* w, float* y,
+                                                               int64_t y_ld, int B, int N, int L, int D) {
+  const int bl = blockIdx.x, b = bl / L, l = bl % L;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float a = 0.f;
+    for (int n = 0; n < N; ++n)
+      a = fmaf(w[((int64_t)b * N + n) * L + l], ld(x, dt, (((int64_t)b * N + n) * L + l) * D + c), a);
+    y[((int64_t)b * L + l) * y_ld + c] = a;
+  }
+}
+
+extern "C" int rf_weighted_msa_sum(const void* x, int dtype, const float* w, float* y, int64_t y_ld, int B, int N, int L,
+                                   int D, void* stream) {
+  RF_CHECK_DT(dtype);
+  hipLaunchKernelGGL(weighted_msa_sum_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, x, dtype, w, y, y_ld, B, N,
+                     L, D);
+  return rf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm over NHWC: statistics (fp64 atomics of per-block fp32 partials) + apply
+// ------------------------------------------------------------------------------------------------
+#define IN_PIX 128  // pixels per block
+__global__ __launch_bounds__(256) void instnorm_stats_kernel(const void* x, int dt, double* sums, int64_t HW, int C) {
+  const int b = blockIdx.y;
+  const int64_t p0 = (int64_t)blockIdx.x * IN_PIX;
+  const int64_t p1 = p0 + IN_PIX < HW ? p0 + IN_PIX : HW;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f, q = 0.f;
+    for (int64_t p = p0; p < p1; ++p) {
+      const float v = ld(x, dt, ((int64_t)b * HW + p) * C + c);
+      s += v;
+      q = fmaf(v, v, q);
+    }
+    atomicAdd(&sums[((int64_t)b * C + c) * 2 + 0], (double)s);
+    atomicAdd(&sums[((int64_t)b * C + c) * 2 + 1], (double)q);
+  }
+}
+
+extern "C" int rf_instnorm_stats(const void* x, int x_dtype, void* sums, int B, int64_t HW, int C, void* stream) {
+  RF_CHECK_DT(x_dtype);
+  hipLaunchKernelGGL(instnorm_stats_kernel, dim3(cdiv(HW, IN_PIX), B), dim3(256), 0, (hipStream_t)stream, x, x_dtype,
+                     (double*)sums, HW, C);
+  return rf_launch_status();
+}
+
+__global__ __launch_bounds__(256) void instnorm_apply_kernel(const void* x, int x_dt, const double* sums,
+                                                             const float* gamma, const float* beta, float eps,
+                                                             const float* residual, int act, void* y, int y_dt,
+                                                             void* y2, int y2_dt, int64_t HW, int C, int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = e % C;
+    const int64_t b = e / (HW * C);
+    const double s = sums[(b * C + c) * 2], q = sums[(b * C + c) * 2 + 1];
+    const double mean = s / (double)HW;
+    double var = q / (double)HW - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = rsqrtf((float)var + eps);
+    float v = (ld(x, x_dt, e) - (float)mean) * rstd * gamma[c] + beta[c];
+    if (residual) v += residual[e];
+    if (act == RF_ACT_ELU) v = elu1(v);
+    st(y, y_dt, e, v);
+    if (y2) st(y2, y2_dt, e, v);
+  }
+}
+
+extern "C" int rf_instnorm_apply(const void* x, int x_dtype, const void* sums, const float* gamma, const float* beta,
+                                 float eps, const float* residual, int act, void* y, int y_dtype, void* y2,
+                                 int y2_dtype, int B, int64_t HW, int C, void* stream) {
+  RF_CHECK_DT(x_dtype);
+  RF_CHECK_DT(y_dtype);
+  const int64_t total = (int64_t)B * HW * C;
+  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(min(cdiv(total, 256), 16384u)), dim3(256), 0, (hipStream_t)stream, x,
+                     x_dtype, (const double*)sums, gamma, beta, eps, residual, act, y, y_dtype, y2, y2_dtype, HW, C,
+                     total);
+  return rf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// embeddings
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void msa_embed_kernel(const int64_t* msa, const int64_t* aa_idx, const float* emb,
+                                                        const float* pe, const float* qenc, float* y, int N, int L,
+                                                        int D, int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = e % D;
+    const int64_t r = e / D;  // (b,n,l)
+    const int l = r % L, n = (r / L) % N;
+    const int64_t b = r / ((int64_t)L * N);
+    y[e] = emb[msa[r] * D + c] + pe[aa_idx[b * L + l] * D + c] + qenc[(n == 0 ? 0 : 1) * D + c];
+  }
+}
+
+extern "C" int rf_msa_embed(const int64_t* msa, const int64_t* aa_idx, const float* emb, const float* pe,
+                            const float* qenc, float* y, int B, int N, int L, int D, void* stream) {
+  const int64_t total = (int64_t)B * N * L * D;
+  hipLaunchKernelGGL(msa_embed_kernel, dim3(min(cdiv(total, 256), 16384u)), dim3(256), 0, (hipStream_t)stream, msa,
+                     aa_idx, emb, pe, qenc, y, N, L, D, total);
+  return rf_launch_status();
+}
+
+__global__ __launch_bounds__(256) void pair_embed_kernel(const int64_t* seq, const int64_t* aa_idx, const float* tl,
+                                                         const float* tr, const float* wsep, const float* bias,
+                                                         const float* pe, float* y, int L, int D, int64_t total) {
+  const int dh = D / 2;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = e % D;
+    const int64_t r = e / D;  // (b,i,j)
+    const int j = r % L, i = (r / L) % L;
+    const int64_t b = r / ((int64_t)L * L);
+    const int64_t ii = aa_idx[b * L + i], jj = aa_idx[b * L + j];
+    const int64_t dd = ii > jj ? ii - jj : jj - ii;
+    const float sep = logf((float)(dd + 1));
+    const float pos = c < dh ? pe[ii * dh + c] : pe[jj * dh + (c - dh)];
+    y[e] = tl[seq[b * L + j] * D + c] + tr[seq[b * L + i] * D + c] + wsep[c] * sep + bias[c] + pos;
+  }
+}
+
+extern "C" int rf_pair_embed(const int64_t* seq, const int64_t* aa_idx, const float* tl, const float* tr,
+                             const float* wsep, const float* bias, const float* pe, float* y, int B, int L, int D,
+                             void* stream) {
+  const int64_t total = (int64_t)B * L * L * D;
+  hipLaunchKernelGGL(pair_embed_kernel, dim3(min(cdiv(total, 256), 16384u)), dim3(256), 0, (hipStream_t)stream, seq,
+                     aa_idx, tl, tr, wsep, bias, pe, y, L, D, total);
+  return rf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic strided copy / cast, axpby
+// ------------------------------------------------------------------------------------------------
+struct Copy4 {
+  int64_t xs[4], ys[4], dims[4];
+};
+__global__ __launch_bounds__(256) void copy4d_kernel(const void* x, int x_dt, void* y, int y_dt, Copy4 c, int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t i3 = e % c.dims[3];
+    int64_t t = e / c.dims[3];
+    const int64_t i2 = t % c.dims[2];
+    t /= c.dims[2];
+    const int64_t i1 = t % c.dims[1], i0 = t / c.dims[1];
+    st(y, y_dt, i0 * c.ys[0] + i1 * c.ys[1] + i2 * c.ys[2] + i3 * c.ys[3],
+       ld(x, x_dt, i0 * c.xs[0] + i1 * c.xs[1] + i2 * c.xs[2] + i3 * c.xs[3]));
+  }
+}
+
+extern "C" int rf_copy4d(const void* x, int x_dtype, const int64_t xs[4], void* y, int y_dtype, const int64_t ys[4],
+                         const int64_t dims[4], void* stream) {
+  RF_CHECK_DT(x_dtype);
+  RF_CHECK_DT(y_dtype);
+  Copy4 c;
+  int64_t total = 1;
+  for (int i = 0; i < 4; ++i) {
+    c.xs[i] = xs[i];
+    c.ys[i] = ys[i];
+    c.dims[i] = dims[i];
+    total *= dims[i];
+  }
+  if (total <= 0) return RF_EINVAL;
+  hipLaunchKernelGGL(copy4d_kernel, dim3(min(cdiv(total, 256), 32768u)), dim3(256), 0, (hipStream_t)stream, x, x_dtype,
+                     y, y_dtype, c, total);
+  return rf_launch_status();
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const void* x, int x_dt, float a, const void* z, int z_dt, float b,
+                                                    void* y, int y_dt, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    float v = a * ld(x, x_dt, e);
+    if (z) v += b * ld(z, z_dt, e);
+    st(y, y_dt, e, v);
+  }
+}
+
+extern "C" int rf_axpby(const void* x, int x_dtype, float a, const void* z, int z_dtype, float b, void* y, int y_dtype,
+                        int64_t n, void* stream) {
+  RF_CHECK_DT(x_dtype);
+  RF_CHECK_DT(y_dtype);
+  hipLaunchKernelGGL(axpby_kernel, dim3(min(cdiv(n, 256), 32768u)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, a, z,
+                     z_dtype, b, y, y_dtype, n);
+  return rf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAVOR+ softmax-kernel features.  One block per (sequence, head) S.
+//   dash layout: [S][n][m_pad] (transposed == 0)  or  [S][m_pad][n] (transposed == 1)
+//   x row r of S: x + s0*xs[0] + s1*xs[1] + s2*xs[2] + r*xs[3], S = (s0*n1 + s1)*n2 + s2
+// ------------------------------------------------------------------------------------------------
+struct FavorP {
+  int64_t xs[4];
+  int n1, n2;
+};
+__global__ __launch_bounds__(256) void favor_softmax_kernel(const void* dash, const void* x, FavorP fp, void* y, int dt,
+                                                            int n, int m, int m_pad, int dh, int is_query,
+                                                            int transposed, float eps) {
+  extern __shared__ float sm[];  // diag[n], rowmax[n]
+  __shared__ float red[4];
+  float* diag = sm;
+  float* rmax = sm + n;
+  const int64_t S = blockIdx.x;
+  const int s2 = S % fp.n2, s1 = (S / fp.n2) % fp.n1;
+  const int64_t s0 = S / ((int64_t)fp.n2 * fp.n1);
+  const int64_t xb = s0 * fp.xs[0] + s1 * fp.xs[1] + s2 * fp.xs[2];
+  const float nrm2 = rsqrtf((float)dh);  // (d^-1/4)^2
+  const float ratio = rsqrtf((float)m);
+  for (int r = threadIdx.x; r < n; r += 256) {
+    float a = 0.f;
+    for (int c = 0; c < dh; ++c) {
+      const float v = ld(x, dt, xb + r * fp.xs[3] + c);
+      a = fmaf(v, v, a);
+    }
+    diag[r] = 0.5f * a * nrm2;
+    rmax[r] = -INFINITY;
+  }
+  __syncthreads();
+  const int64_t base = S * (int64_t)n * m_pad;
+  const int64_t tot = (int64_t)n * m_pad;
+  // pass 1: maxima.  e runs over the stored layout so loads are coalesced.
+  float gmax = -INFINITY;
+  if (is_query) {
+    // per-row max over the valid features: one wave per row
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int r = wv; r < n; r += 4) {
+      float mx = -INFINITY;
+      for (int f = lane; f < m; f += 64)
+        mx = fmaxf(mx, ld(dash, dt, base + (transposed ? (int64_t)f * n + r : (int64_t)r * m_pad + f)));
+      mx = wave_max(mx);
+      if (lane == 0) rmax[r] = mx;
+    }
+    __syncthreads();
+  } else {
+    for (int64_t e = threadIdx.x; e < tot; e += 256) {
+      const int f = transposed ? e / n : e % m_pad;
+      if (f < m) gmax = fmaxf(gmax, ld(dash, dt, base + e));
+    }
+    gmax = block_max(gmax, red);
+  }
+  for (int64_t e = threadIdx.x; e < tot; e += 256) {
+    const int f = transposed ? e / n : e % m_pad;
+    const int r = transposed ? e % n : e / m_pad;
+    float o = 0.f;
+    if (f < m) {
+      const float mx = is_query ? rmax[r] : gmax;
+      o = ratio * (__expf(ld(dash, dt, base + e) - diag[r] - mx) + eps);
+    }
+    st(y, dt, base + e, o);
+  }
+}
+
+extern "C" int rf_favor_softmax_features(const void* dash, const void* x, const int64_t xs[4], int n1, int n2, void* y,
+                                         int dtype, int64_t S, int n, int m, int m_pad, int dh, int is_query,
+                                         int transposed, float eps, void* stream) {
+  RF_CHECK_DT(dtype);
+  FavorP fp;
+  for (int i = 0; i < 4; ++i) fp.xs[i] = xs[i];
+  fp.n1 = n1;
+  fp.n2 = n2;
+  hipLaunchKernelGGL(favor_softmax_kernel, dim3((unsigned)S), dim3(256), 2 * n * sizeof(float), (hipStream_t)stream,
+                     dash, x, fp, y, dtype, n, m, m_pad, dh, is_query, transposed, eps);
+  return rf_launch_status();
+}
+
+// y[r, c] = num[r, c] / num[r, dh]  (c < dh)
+__global__ __launch_bounds__(256) void linattn_norm_kernel(const float* num, int64_t num_ld, void* y, int y_dt,
+                                                           int64_t y_ld, int64_t rows, int dh) {
+  const int64_t total = rows * dh;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = e % dh;
+    const int64_t r = e / dh;
+    st(y, y_dt, r * y_ld + c, num[r * num_ld + c] / num[r * num_ld + dh]);
+  }
+}
+
+extern "C" int rf_linattn_normalize(const float* num, int64_t num_ld, void* y, int y_dtype, int64_t y_ld, int64_t rows,
+                                    int dh, void* stream) {
+  RF_CHECK_DT(y_dtype);
+  const int64_t total = rows * dh;
+  hipLaunchKernelGGL(linattn_norm_kernel, dim3(min(cdiv(total, 256), 32768u)), dim3(256), 0, (hipStream_t)stream, num,
+                     num_ld, y, y_dtype, y_ld, rows, dh);
+  return rf_launch_status();
+}
+
+// feat[b,i,j,c0 + c] = msa1d[b,i,c] (c < P2) ; feat[b,i,j,c0+P2+c] = msa1d[b,j,c]
+__global__ __launch_bounds__(256) void tile_1d_kernel(const float* m1, void* feat, int dt, int64_t ld_, int c0, int L,
+                                                      int P2, int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = e % (2 * P2);
+    const int64_t r = e / (2 * P2);
+    const int j = r % L, i = (r / L) % L;
+    const int64_t b = r / ((int64_t)L * L);
+    const float v = c < P2 ? m1[(b * L + i) * P2 + c] : m1[(b * L + j) * P2 + (c - P2)];
+    st(feat, dt, r * ld_ + c0 + c, v);
+  }
+}
+
+extern "C" int rf_tile_1d_feats(const float* msa1d, void* feat, int dtype, int64_t feat_ld, int c0, int B, int L, int P2,
+                                void* stream) {
+  RF_CHECK_DT(dtype);
+  const int64_t total = (int64_t)B * L * L * 2 * P2;
+  hipLaunchKernelGGL(tile_1d_kernel, dim3(min(cdiv(total, 256), 32768u)), dim3(256), 0, (hipStream_t)stream, msa1d, feat,
+                     dtype, feat_ld, c0, L, P2, total);
+  return rf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GraphTransformer attention core: block per (b,i), thread per (h,d) channel (H*d <= 256)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void graph_attention_kernel(const void* q, const void* k, const void* v, const void* e,
+                                                              int dt, float* out, int L, int H, int d, float scale) {
+  extern __shared__ float sm[];  // logits [H][L]
+  const int bi = blockIdx.x, b = bi / L;
+  const int HD = H * d;
+  const int t = threadIdx.x;
+  const bool act = t < HD;
+  const int h = act ? t / d : 0;
+  const float qv = act ? ld(q, dt, (int64_t)bi * HD + t) : 0.f;
+  // phase 1: logits[h][j] = scale * sum_d q (k_j + e_ij)
+  for (int j = 0; j < L; ++j) {
+    float p = 0.f;
+    if (act) p = qv * (ld(k, dt, ((int64_t)b * L + j) * HD + t) + ld(e, dt, ((int64_t)bi * L + j) * HD + t));
+    // reduce over the d lanes of this head (d is a power of two <= 64 and heads are lane-aligned)
+    for (int o = d >> 1; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+    if (act && (t % d) == 0) sm[h * L + j] = p * scale;
+  }
+  __syncthreads();
+  const int lane = t & 63, wv = t >> 6;
+  for (int hh = wv; hh < H; hh += 4) {
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) mx = fmaxf(mx, sm[hh * L + j]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int j = lane; j < L; j += 64) s += __expf(sm[hh * L + j] - mx);
+    const float inv = 1.f / wave_sum(s);
+    for (int j = lane; j < L; j += 64) sm[hh * L + j] = __expf(sm[hh * L + j] - mx) * inv;
+  }
+  __syncthreads();
+  if (act) {
+    float a = 0.f;
+    for (int j = 0; j < L; ++j)
+      a = fmaf(sm[h * L + j], ld(v, dt, ((int64_t)b * L + j) * HD + t) + ld(e, dt, ((int64_t)bi * L + j) * HD + t), a);
+    out[(int64_t)bi * HD + t] = a;
+  }
+}
+
+extern "C" int rf_graph_attention(const void* q, const void* k, const void* v, const void* e, int dtype, float* out,
+                                  int B, int L, int H, int d, float scale, void* stream) {
+  RF_CHECK_DT(dtype);
+  if (H * d > 256 || d > 64 || (d & (d - 1)) != 0) return RF_EINVAL;
+  const size_t lds = (size_t)H * L * sizeof(float);
+  if (lds > 64 * 1024) return RF_EINVAL;
+  hipLaunchKernelGGL(graph_attention_kernel, dim3(B * L), dim3(256), lds, (hipStream_t)stream, q, k, v, e, dtype, out, L,
+                     H, d, scale);
+  return rf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// distance-masked attention map: block per (b,i); att[b,h,i,:]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dist_att_kernel(const float* q, const float* k, const float* xyz,
+                                                       const float* bins, void* att, int dt, int L, int H, int dq) {
+  extern __shared__ float sm[];  // [H][L]
+  const int bi = blockIdx.x, b = bi / L, i = bi % L;
+  const float cx = xyz[((int64_t)bi * 3 + 1) * 3 + 0], cy = xyz[((int64_t)bi * 3 + 1) * 3 + 1],
+              cz = xyz[((int64_t)bi * 3 + 1) * 3 + 2];
+  for (int e = threadIdx.x; e < H * L; e += 256) {
+    const int h = e / L, j = e % L;
+    const float* qr = q + ((int64_t)bi * H + h) * dq;
+    const float* kr = k + (((int64_t)b * L + j) * H + h) * dq;
+    float a = 0.f;
+    for (int c = 0; c < dq; ++c) a = fmaf(qr[c], kr[c], a);
+    const float* cj = xyz + (((int64_t)b * L + j) * 3 + 1) * 3;
+    const float dx = cx - cj[0], dy = cy - cj[1], dz = cz - cj[2];
+    const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+    sm[e] = a + (dist < bins[h] ? 0.f : -1e9f);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int h = wv; h < H; h += 4) {
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) mx = fmaxf(mx, sm[h * L + j]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int j = lane; j < L; j += 64) s += __expf(sm[h * L + j] - mx);
+    const float inv = 1.f / wave_sum(s);
+    for (int j = lane; j < L; j += 64)
+      st(att, dt, (((int64_t)b * H + h) * L + i) * L + j, __expf(sm[h * L + j] - mx) * inv);
+  }
+}
+
+extern "C" int rf_dist_masked_attention(const float* q, const float* k, const float* xyz, const float* bins, void* att,
+                                        int att_dtype, int B, int L, int H, int dq, void* stream) {
+  RF_CHECK_DT(att_dtype);
+  const size_t lds = (size_t)H * L * sizeof(float);
+  if (lds > 64 * 1024) return RF_EINVAL;
+  hipLaunchKernelGGL(dist_att_kernel, dim3(B * L), dim3(256), lds, (hipStream_t)stream, q, k, xyz, bins, att, att_dtype,
+                     L, H, dq);
+  return rf_launch_status();
+}
+
+extern "C" int rf_version(void) { return 1; }
+extern "C" const char* rf_build_info(void) { return "librfmi gfx950 (MI355X) round-1"; }

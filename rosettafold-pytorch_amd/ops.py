@@ -1,0 +1,313 @@
+"""Thin Python wrappers over the C ABI of librfmi.so (include/rfmi.h).
+
+PyTorch is used here for device memory (tensors), the current HIP stream and dtype tags only;
+every arithmetic step is a kernel of librfmi.so reached through ctypes with raw device pointers.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import lib, check, GemmDesc, I64x4
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def dcode(dtype):
+    if dtype == torch.float32:
+        return L.RF_F32
+    if dtype == torch.bfloat16:
+        return L.RF_BF16
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, off_elems=0):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr() + off_elems * t.element_size())
+
+
+def _i4(v):
+    return C.byref(I64x4(*[int(x) for x in v]))
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.RfmiError("librfmi ops need device tensors (there is no CPU fallback)")
+
+
+# --------------------------------------------------------------------------------------------- GEMM
+def gemm(A, B, Cout, M, N, K, *, batch=(1, 1, 1), a_off=0, b_off=0, c_off=0,
+         a_bs=(0, 0, 0), a_row=(0, 0, None), a_ko=0,
+         b_bs=(0, 0, 0), b_row=(0, 0, None), b_ko=0, kc=0,
+         c_bs=(0, 0, 0), c_row=(0, 0, None), c_col=(0, 0),
+         bias=None, bias_mode=None, act=L.ACT_NONE, act_nvalid=0, act_eps=0.0, alpha=1.0,
+         residual=None, res_off=None, conv=None, tile_cfg=0):
+    """C = epilogue(alpha * A @ B^T) with the strided/batched/chunked addressing of rf_gemm_desc.
+    *_row = (rc, ro, ri): offset(m) = (m // rc)*ro + (m % rc)*ri, rc=0 -> m*ri.  ri=None -> K (A,B) / N (C).
+    c_col = (cc, co).  Offsets are in elements.  conv = (n, h, w, c, dilation) selects implicit 3x3 im2col."""
+    _need_cuda(A, B, Cout, bias, residual)
+    if A.dtype != B.dtype:
+        raise TypeError("A and B dtypes differ")
+    d = GemmDesc()
+    d.M, d.N, d.K = int(M), int(N), int(K)
+    d.nb0, d.nb1, d.nb2 = [int(x) for x in batch]
+    d.ab_dtype, d.c_dtype = dcode(A.dtype), dcode(Cout.dtype)
+    d.kc = int(kc)
+    d.a_rc, d.a_ro, d.a_ri = int(a_row[0]), int(a_row[1]), int(K if a_row[2] is None else a_row[2])
+    d.b_rc, d.b_ro, d.b_ri = int(b_row[0]), int(b_row[1]), int(K if b_row[2] is None else b_row[2])
+    d.c_rc, d.c_ro, d.c_ri = int(c_row[0]), int(c_row[1]), int(N if c_row[2] is None else c_row[2])
+    d.c_cc, d.c_co = int(c_col[0]), int(c_col[1])
+    for i in range(3):
+        d.a_bs[i], d.b_bs[i], d.c_bs[i] = int(a_bs[i]), int(b_bs[i]), int(c_bs[i])
+    d.a_ko, d.b_ko = int(a_ko), int(b_ko)
+    if conv is not None:
+        d.a_mode = L.AMODE_CONV3X3
+        d.conv_n, d.conv_h, d.conv_w, d.conv_c, d.conv_dil = [int(x) for x in conv]
+    if bias is not None:
+        if bias.dtype != F32:
+            raise TypeError("bias must be fp32")
+        d.bias_mode = L.BIAS_COL if bias_mode is None else bias_mode
+        d.bias = bias.data_ptr()
+    d.act, d.act_nvalid, d.act_eps, d.alpha = int(act), int(act_nvalid), float(act_eps), float(alpha)
+    d.tile_cfg = int(tile_cfg)
+    d.A = A.data_ptr() + a_off * A.element_size()
+    d.B = B.data_ptr() + b_off * B.element_size()
+    d.C = Cout.data_ptr() + c_off * Cout.element_size()
+    if residual is not None:
+        if residual.dtype != F32:
+            raise TypeError("residual must be fp32")
+        d.residual = residual.data_ptr() + (c_off if res_off is None else res_off) * 4
+    check(lib.rf_gemm(C.byref(d), stream()), "rf_gemm")
+    return Cout
+
+
+def linear(x, w, bias=None, *, out=None, out_dtype=None, act=L.ACT_NONE, residual=None, alpha=1.0, tile_cfg=0):
+    """out[..., N] = act(x[..., K] @ w[N, K]^T + bias) (+ residual).  x contiguous, w [N, Kw>=K] contiguous."""
+    K = x.shape[-1]
+    Mrows = x.numel() // K
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"linear: K mismatch {w.shape} vs {x.shape}")
+    if out is None:
+        out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=out_dtype or x.dtype)
+    gemm(x, w, out, Mrows, N, K, bias=bias, act=act, residual=residual, alpha=alpha, tile_cfg=tile_cfg)
+    return out
+
+
+# --------------------------------------------------------------------------------------------- norms
+def layernorm(x, gamma, beta, *, eps=1e-5, out=None, out_dtype=None, out_ld=None, out_off=0, rows=None, D=None,
+              x_ld=None, groups=1, act=L.ACT_NONE):
+    D = x.shape[-1] if D is None else D
+    rows = x.numel() // D if rows is None else rows
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
+    _need_cuda(x, out, gamma, beta)
+    check(lib.rf_layernorm(ptr(x), dcode(x.dtype), D if x_ld is None else x_ld, ptr(out, out_off), dcode(out.dtype),
+                           D if out_ld is None else out_ld, rows, D, ptr(gamma), ptr(beta), eps, groups, act,
+                           stream()), "rf_layernorm")
+    return out
+
+
+def sym_layernorm(pair, out_dtype, eps=1e-5):
+    B, L_, _, D = pair.shape
+    out = torch.empty(pair.shape, device=pair.device, dtype=out_dtype)
+    _need_cuda(pair)
+    check(lib.rf_sym_layernorm(ptr(pair), ptr(out), dcode(out_dtype), B, L_, D, eps, stream()), "rf_sym_layernorm")
+    return out
+
+
+def softmax(x, x_off, x_rs, x_cs, y, y_off, y_rs, rows, cols, scale=1.0):
+    _need_cuda(x, y)
+    check(lib.rf_softmax(ptr(x, x_off), x_rs, x_cs, ptr(y, y_off), dcode(y.dtype), y_rs, rows, cols, scale, stream()),
+          "rf_softmax")
+
+
+def tied_softmax(logits, att, att_sym=None, sym_ld=0):
+    B, H, L_, _ = logits.shape
+    _need_cuda(logits, att, att_sym)
+    check(lib.rf_tied_softmax(ptr(logits), ptr(att), dcode(att.dtype), ptr(att_sym), sym_ld, B, H, L_, stream()),
+          "rf_tied_softmax")
+
+
+def poswise(q0, q0_ld, k, k_ld, k_col0, w, q_scale, qs_ld, qs_col0, B, N, L_, H, dh, scale, qscale):
+    _need_cuda(q0, k, w, q_scale)
+    check(lib.rf_poswise(ptr(q0), q0_ld, ptr(k), k_ld, k_col0, ptr(w), ptr(q_scale), qs_ld, qs_col0, dcode(k.dtype),
+                         B, N, L_, H, dh, scale, qscale, stream()), "rf_poswise")
+
+
+def weighted_msa_sum(x, w, y, y_ld):
+    B, N, L_, D = x.shape
+    _need_cuda(x, w, y)
+    check(lib.rf_weighted_msa_sum(ptr(x), dcode(x.dtype), ptr(w), ptr(y), y_ld, B, N, L_, D, stream()),
+          "rf_weighted_msa_sum")
+
+
+def instnorm(x, gamma, beta, *, eps=1e-6, residual=None, act=L.ACT_NONE, out_dtype=None, out2_dtype=None):
+    """InstanceNorm2d(affine) over NHWC x [B,H,W,C]; returns (y, y2) where y2 is an optional second copy."""
+    B, H, W, Cc = x.shape
+    _need_cuda(x, gamma, beta, residual)
+    sums = torch.zeros(B * Cc * 2, device=x.device, dtype=torch.float64)
+    check(lib.rf_instnorm_stats(ptr(x), dcode(x.dtype), ptr(sums), B, H * W, Cc, stream()), "rf_instnorm_stats")
+    y = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
+    y2 = torch.empty(x.shape, device=x.device, dtype=out2_dtype) if out2_dtype is not None else None
+    check(lib.rf_instnorm_apply(ptr(x), dcode(x.dtype), ptr(sums), ptr(gamma), ptr(beta), eps, ptr(residual), act,
+                                ptr(y), dcode(y.dtype), ptr(y2), dcode(y2.dtype) if y2 is not None else 0, B, H * W,
+                                Cc, stream()), "rf_instnorm_apply")
+    return y, y2
+
+
+# --------------------------------------------------------------------------------------------- misc
+def msa_embed(msa, aa_idx, emb, pe, qenc):
+    B, N, L_ = msa.shape
+    D = emb.shape[1]
+    y = torch.empty(B, N, L_, D, device=msa.device, dtype=F32)
+    _need_cuda(msa, aa_idx, emb, pe, qenc)
+    check(lib.rf_msa_embed(ptr(msa), ptr(aa_idx), ptr(emb), ptr(pe), ptr(qenc), ptr(y), B, N, L_, D, stream()),
+          "rf_msa_embed")
+    return y
+
+
+def pair_embed(seq, aa_idx, tl, tr, wsep, bias, pe):
+    B, L_ = seq.shape
+    D = tl.shape[1]
+    y = torch.empty(B, L_, L_, D, device=seq.device, dtype=F32)
+    _need_cuda(seq, aa_idx, tl, tr, wsep, bias, pe)
+    check(lib.rf_pair_embed(ptr(seq), ptr(aa_idx), ptr(tl), ptr(tr), ptr(wsep), ptr(bias), ptr(pe), ptr(y), B, L_, D,
+                            stream()), "rf_pair_embed")
+    return y
+
+
+def copy4d(x, xs, y, ys, dims, x_off=0, y_off=0):
+    _need_cuda(x, y)
+    check(lib.rf_copy4d(ptr(x, x_off), dcode(x.dtype), _i4(xs), ptr(y, y_off), dcode(y.dtype), _i4(ys), _i4(dims),
+                        stream()), "rf_copy4d")
+    return y
+
+
+def cast(x, dtype):
+    """contiguous copy of x in another dtype."""
+    if x.dtype == dtype:
+        return x
+    y = torch.empty(x.shape, device=x.device, dtype=dtype)
+    axpby(x, 1.0, None, 0.0, y)
+    return y
+
+
+def axpby(x, a, z, b, y):
+    _need_cuda(x, z, y)
+    check(lib.rf_axpby(ptr(x), dcode(x.dtype), a, ptr(z), dcode(z.dtype) if z is not None else 0, b, ptr(y),
+                       dcode(y.dtype), x.numel(), stream()), "rf_axpby")
+    return y
+
+
+def favor_softmax_features(dash, x, x_off, xs, n1, n2, S, n, m, m_pad, dh, is_query, transposed, eps=1e-4):
+    _need_cuda(dash, x)
+    check(lib.rf_favor_softmax_features(ptr(dash), ptr(x, x_off), _i4(xs), n1, n2, ptr(dash), dcode(dash.dtype), S, n,
+                                        m, m_pad, dh, is_query, transposed, eps, stream()),
+          "rf_favor_softmax_features")
+
+
+def linattn_normalize(num, num_ld, y, y_ld, rows, dh):
+    _need_cuda(num, y)
+    check(lib.rf_linattn_normalize(ptr(num), num_ld, ptr(y), dcode(y.dtype), y_ld, rows, dh, stream()),
+          "rf_linattn_normalize")
+
+
+def tile_1d_feats(msa1d, feat, feat_ld, c0, B, L_, P2):
+    _need_cuda(msa1d, feat)
+    check(lib.rf_tile_1d_feats(ptr(msa1d), ptr(feat), dcode(feat.dtype), feat_ld, c0, B, L_, P2, stream()),
+          "rf_tile_1d_feats")
+
+
+def graph_attention(q, k, v, e, out, B, L_, H, d, scale):
+    _need_cuda(q, k, v, e, out)
+    check(lib.rf_graph_attention(ptr(q), ptr(k), ptr(v), ptr(e), dcode(q.dtype), ptr(out), B, L_, H, d, scale,
+                                 stream()), "rf_graph_attention")
+
+
+def dist_masked_attention(q, k, xyz, bins, att, B, L_, H, dq):
+    _need_cuda(q, k, xyz, bins, att)
+    check(lib.rf_dist_masked_attention(ptr(q), ptr(k), ptr(xyz), ptr(bins), ptr(att), dcode(att.dtype), B, L_, H, dq,
+                                       stream()), "rf_dist_masked_attention")
+
+
+# --------------------------------------------------------------------------------------------- SE(3)
+def knn_mask(xyz, aa_idx, k, kmin=9):
+    B, L_ = xyz.shape[:2]
+    mask = torch.empty(B, L_, L_, device=xyz.device, dtype=torch.uint8)
+    _need_cuda(xyz, aa_idx)
+    check(lib.rf_knn_mask(ptr(xyz), ptr(aa_idx), ptr(mask), B, L_, k, kmin, stream()), "rf_knn_mask")
+    return mask
+
+
+def edges_from_mask(mask, capacity):
+    B, L_, _ = mask.shape
+    dev = mask.device
+    src = torch.zeros(capacity, device=dev, dtype=torch.int32)
+    dst = torch.zeros(capacity, device=dev, dtype=torch.int32)
+    eid = torch.empty(B, L_, L_, device=dev, dtype=torch.int32)
+    count = torch.zeros(1, device=dev, dtype=torch.int32)
+    ws = torch.empty(2 * B * L_, device=dev, dtype=torch.int32)
+    check(lib.rf_edges_from_mask(ptr(mask), ptr(src), ptr(dst), ptr(eid), ptr(count), ptr(ws), B, L_, stream()),
+          "rf_edges_from_mask")
+    return src, dst, eid, count
+
+
+def se3_edge_geometry(xyz, edge_emb, src, dst, count, capacity):
+    B, L_ = xyz.shape[:2]
+    de = edge_emb.shape[-1]
+    basis = torch.empty(capacity, 34, device=xyz.device, dtype=F32)
+    feat = torch.empty(capacity, de + 1, device=xyz.device, dtype=F32)
+    _need_cuda(xyz, edge_emb)
+    check(lib.rf_se3_edge_geometry(ptr(xyz), ptr(edge_emb), ptr(src), ptr(dst), ptr(count), ptr(basis), ptr(feat),
+                                   de + 1, L_, de, capacity, stream()), "rf_se3_edge_geometry")
+    return basis, feat
+
+
+def se3_message(R0, R1, basis, h0, h1, src, count, mo, dout, mi0, mi1, capacity):
+    msg = torch.zeros(capacity, mo, 2 * dout + 1, device=basis.device, dtype=F32)
+    check(lib.rf_se3_message(ptr(R0), ptr(R1), ptr(basis), ptr(h0), ptr(h1), ptr(src), ptr(count), ptr(msg), mo, dout,
+                             mi0, mi1, capacity, stream()), "rf_se3_message")
+    return msg
+
+
+def se3_attention(k0, k1, q0, q1, v0, v1, eid, heads, mk0, mk1, mv0, mv1, V, L_):
+    dev = k0.device
+    out0 = torch.empty(V, mv0, 1, device=dev, dtype=F32)
+    out1 = torch.empty(V, mv1, 3, device=dev, dtype=F32)
+    check(lib.rf_se3_attention(ptr(k0), ptr(k1), ptr(q0), ptr(q1), ptr(v0), ptr(v1), ptr(eid), ptr(out0), ptr(out1),
+                               heads, mk0, mk1, mv0, mv1, V, L_, stream()), "rf_se3_attention")
+    return out0, out1
+
+
+def se3_norm_bias(v, bias, deg):
+    V, m, _ = v.shape
+    y = torch.empty_like(v)
+    check(lib.rf_se3_norm_bias(ptr(v), ptr(bias), ptr(y), V, m, deg, stream()), "rf_se3_norm_bias")
+    return y
+
+
+def se3_gram(v, deg):
+    V, m, _ = v.shape
+    s = torch.empty(V, m * m, device=v.device, dtype=F32)
+    check(lib.rf_se3_gram(ptr(v), ptr(s), V, m, deg, stream()), "rf_se3_gram")
+    return s
+
+
+def se3_attn_apply(att, x, m_out, deg):
+    V, m_in, nc = x.shape
+    y = torch.empty(V, m_out, nc, device=x.device, dtype=F32)
+    check(lib.rf_se3_attn_apply(ptr(att), ptr(x), ptr(y), V, m_out, m_in, deg, stream()), "rf_se3_attn_apply")
+    return y
+
+
+def coord_apply(xyz, disp):
+    out = torch.empty_like(xyz)
+    check(lib.rf_coord_apply(ptr(xyz), ptr(disp), ptr(out), xyz.shape[0] * xyz.shape[1], stream()), "rf_coord_apply")
+    return out

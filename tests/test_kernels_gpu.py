@@ -1,0 +1,145 @@
+"""GPU parity tests of the librfmi kernels against plain fp32 PyTorch formulas of the same op.
+bf16 tolerances: operands are rounded to bf16 (rel 2^-8), accumulation is fp32."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from rosettafold_pytorch_amd import ops, _lib as L  # noqa: E402
+
+DEV = "cuda"
+
+
+def rel_err(a, b):
+    return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-20)).item()
+
+
+def randn(*s, dtype=torch.float32, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(s))
+    return torch.randn(*s, generator=g).to(DEV).to(dtype)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float32, 2e-5)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 288, 288), (1024, 384, 384), (130, 37, 96), (64, 80, 128),
+                                   (257, 1152, 288), (96, 288, 1152), (512, 96, 736)])
+def test_linear(dtype, tol, M, N, K):
+    x, w, b = randn(M, K, dtype=dtype), randn(N, K, dtype=dtype, seed=1), randn(N, seed=2)
+    ref = x.float() @ w.float().t() + b
+    for out_dtype in (torch.float32, dtype):
+        y = ops.linear(x, w, b, out_dtype=out_dtype)
+        assert rel_err(y, ref) < tol, (M, N, K, out_dtype)
+    res = randn(M, N, seed=3)
+    y = ops.linear(x, w, b, out_dtype=torch.float32, act=L.ACT_RELU, residual=res)
+    assert rel_err(y, torch.relu(ref) + res) < tol
+
+
+@pytest.mark.parametrize("cfg", list(range(1, 13)))
+def test_gemm_all_tile_configs(cfg):
+    M, N, K = 333, 200, 352
+    x, w = randn(M, K, dtype=torch.bfloat16), randn(N, K, dtype=torch.bfloat16, seed=1)
+    y = ops.linear(x, w, None, out_dtype=torch.float32, tile_cfg=cfg)
+    assert rel_err(y, x.float() @ w.float().t()) < 1e-2
+
+
+def test_gemm_exact_integers_layout():
+    """A = small integers, asymmetric B: any row/col swap or k permutation shows up exactly."""
+    M, N, K = 128, 96, 64
+    a = (torch.arange(M * K).reshape(M, K) % 7 - 3).float()
+    b = ((torch.arange(N * K).reshape(N, K) * 3 + torch.arange(N)[:, None]) % 5 - 2).float()
+    y = ops.linear(a.to(DEV).bfloat16(), b.to(DEV).bfloat16(), None, out_dtype=torch.float32)
+    assert torch.equal(y.cpu(), a @ b.t())
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float32, 2e-5)])
+def test_gemm_batched_chunked(dtype, tol):
+    """tied-attention logits: logits[b,h,i,j] = sum_{n,d} q[b,n,i,h,d] k[b,n,j,h,d]  (rf.py:254)."""
+    B, N, Lr, H, dh = 2, 5, 40, 3, 8
+    D = H * dh
+    qk = randn(B, N, Lr, 2 * D, dtype=dtype)
+    q, k = qk[..., :D].float().view(B, N, Lr, H, dh), qk[..., D:].float().view(B, N, Lr, H, dh)
+    ref = torch.einsum("bnihd,bnjhd->bhij", q, k)
+    out = torch.empty(B, H, Lr, Lr, device=DEV, dtype=torch.float32)
+    ops.gemm(qk, qk, out, Lr, Lr, N * dh, batch=(B, H, 1), b_off=D,
+             a_bs=(N * Lr * 2 * D, dh, 0), a_row=(0, 0, 2 * D), a_ko=Lr * 2 * D,
+             b_bs=(N * Lr * 2 * D, dh, 0), b_row=(0, 0, 2 * D), b_ko=Lr * 2 * D, kc=dh,
+             c_bs=(H * Lr * Lr, Lr * Lr, 0), c_row=(0, 0, Lr))
+    assert rel_err(out, ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float32, 2e-5)])
+def test_gemm_split_rows_cols(dtype, tol):
+    """att @ v with v stored transposed [b,n,(h,d),l] and the output scattered to [b,n,l,(h,d)] (rf.py:257-258)."""
+    B, N, Lr, H, dh = 2, 3, 24, 2, 8
+    D = H * dh
+    att = randn(B, H, Lr, Lr, dtype=dtype)
+    v_t = randn(B, N, D, Lr, dtype=dtype, seed=5)
+    ref = torch.einsum("bhij,bnhdj->bnihd", att.float(), v_t.float().view(B, N, H, dh, Lr)).reshape(B, N, Lr, D)
+    out = torch.empty(B, N, Lr, D, device=DEV, dtype=dtype)
+    ops.gemm(att, v_t, out, Lr, N * dh, Lr, batch=(B, H, 1),
+             a_bs=(H * Lr * Lr, Lr * Lr, 0), a_row=(0, 0, Lr),
+             b_bs=(N * D * Lr, dh * Lr, 0), b_row=(dh, D * Lr, Lr),
+             c_bs=(N * Lr * D, dh, 0), c_row=(0, 0, D), c_col=(dh, Lr * D))
+    assert rel_err(out, ref) < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float32, 3e-5)])
+@pytest.mark.parametrize("dil", [1, 2, 4])
+def test_conv3x3(dtype, tol, dil):
+    B, Hh, Ww, Cc, Co = 2, 19, 19, 24, 40
+    x = randn(B, Hh, Ww, Cc, dtype=dtype)
+    w = randn(Co, Cc, 3, 3, dtype=dtype, seed=1)
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), padding="same", dilation=dil)
+    wk = w.permute(0, 2, 3, 1).reshape(Co, 9 * Cc).contiguous()
+    out = torch.empty(B, Hh, Ww, Co, device=DEV, dtype=torch.float32)
+    ops.gemm(x, wk, out, B * Hh * Ww, Co, 9 * Cc, conv=(B, Hh, Ww, Cc, dil))
+    assert rel_err(out, ref.permute(0, 2, 3, 1)) < tol
+
+
+def test_relu_eps_epilogue():
+    M, N, K = 70, 288, 64
+    x, w = randn(M, K, dtype=torch.bfloat16), randn(N, K, dtype=torch.bfloat16, seed=1)
+    y = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(x, w, y, M, N, K, act=L.ACT_RELU_EPS, act_nvalid=266, act_eps=1e-3)
+    ref = torch.relu(x.float() @ w.float().t()) + 1e-3
+    ref[:, 266:] = 0
+    assert rel_err(y, ref) < 2e-2 and (y[:, 266:] == 0).all()
+    ops.gemm(w, x, (yt := torch.empty(N, M, device=DEV, dtype=torch.bfloat16)), N, M, K, act=L.ACT_RELU_EPS,
+             act_nvalid=-266, act_eps=1e-3)
+    assert rel_err(yt, ref.t()) < 2e-2 and (yt[266:] == 0).all()
+
+
+@pytest.mark.parametrize("D", [32, 72, 288, 384, 1024, 2304])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_layernorm(D, dtype):
+    x = randn(37, D) * 3 + 1
+    g, b = randn(D, seed=1), randn(D, seed=2)
+    ref = torch.nn.functional.layer_norm(x, (D,), g, b)
+    y = ops.layernorm(x, g, b, out_dtype=dtype)
+    assert rel_err(y, ref) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+def test_softmax_and_tied():
+    B, H, Lr = 2, 3, 50
+    lg = randn(B, H, Lr, Lr) * 4
+    att = torch.empty(B, H, Lr, Lr, device=DEV, dtype=torch.float32)
+    sym = torch.empty(B, Lr, Lr, H, device=DEV, dtype=torch.float32)
+    ops.tied_softmax(lg, att, sym, H)
+    ref = lg.softmax(-1)
+    assert rel_err(att, ref) < 1e-5
+    assert rel_err(sym, (0.5 * (ref + ref.transpose(-1, -2))).permute(0, 2, 3, 1)) < 1e-5
+    assert torch.equal(sym, sym.transpose(1, 2))  # reference tests/test_module.py:406-413
+
+
+def test_instnorm():
+    B, Hh, Cc = 2, 21, 24
+    x = randn(B, Hh, Hh, Cc) * 2 + 0.5
+    g, b, r = randn(Cc, seed=1), randn(Cc, seed=2), randn(B, Hh, Hh, Cc, seed=3)
+    ref = torch.nn.functional.instance_norm(x.permute(0, 3, 1, 2), weight=g, bias=b, eps=1e-6).permute(0, 2, 3, 1)
+    y, y2 = ops.instnorm(x, g, b, residual=r, act=L.ACT_ELU, out_dtype=torch.float32, out2_dtype=torch.bfloat16)
+    assert rel_err(y, torch.nn.functional.elu(ref + r)) < 1e-5
+    assert rel_err(y2, y) < 1e-2
