@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- residues/s of the RoseTTAFold forward path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one forward of the full model (config 2 of BASELINE.json: B=4 MSAs of N=128 x L=256 per GPU,
+d_msa=384, d_pair=288, 8 two-track + 4 three-track + final block, 4 encoder layers) on synthetic token
+inputs already resident in HBM, random-init weights.  Independent MSAs shard across ranks (one process
+per GPU); the only collective is the gather of the results to rank 0 (RCCL), inside the timed region.
+Rank 0 prints ONE JSON line.  Extra legs on rank 0 at N=1:
+  * roofline: the dominant kernel (the bf16 MFMA GEMM engine, 128x128 tile family) timed live with HIP events
+    around every launch of one extra profiled step; achieved = algorithmic FLOPs of those launches / their time.
+  * cpu_baseline: the CPU oracle (oracle/rf_oracle.py, a restatement pinned to the reference's golden vectors)
+    timed on the host cores on one block of each kind at config-2 shapes (B=1), scaled by the block counts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[0] with the constructible d_msa: plumbing case
+    1: dict(B=1, N=8, L=64, model=dict(d_msa=96, d_pair=64, d_node=8, d_edge=8, d_state=8, n_two_track_blocks=1,
+                                       n_three_track_blocks=2, n_encoder_layers=1, max_len=64,
+                                       n_neighbors=[128, 128])),
+    # configs[1]: the configuration the metric is quoted on (README hyper-parameters of the reference)
+    2: dict(B=4, N=128, L=256, model=dict(d_msa=384, d_pair=288, d_node=32, d_edge=32, d_state=32,
+                                          n_two_track_blocks=8, n_three_track_blocks=5, n_encoder_layers=4,
+                                          max_len=260, n_neighbors=[128, 128, 64, 64, 64])),
+}
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def make_inputs(B, N, L, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    msa = torch.randint(0, 21, (B, N, L), generator=g)
+    seq = msa[:, 0].clone()
+    aa_idx = torch.arange(L).unsqueeze(0).repeat(B, 1)
+    return msa.to(device), seq.to(device), aa_idx.to(device)
+
+
+def profile_gemms(model, inputs):
+    """One extra forward with HIP events around every rf_gemm launch (same stream the kernels run on)."""
+    from rosettafold_pytorch_amd import ops
+    recs = []
+    orig = ops.lib.rf_gemm
+
+    def wrapped(desc, stream):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = orig(desc, stream)
+        e.record()
+        d = desc._obj
+        nb = max(d.nb0, 1) * max(d.nb1, 1) * max(d.nb2, 1)
+        recs.append((s, e, 2.0 * d.M * d.N * d.K * nb, d.ab_dtype, d.M, d.N, d.K, nb, d.a_mode))
+        return rc
+
+    ops.lib.rf_gemm = wrapped
+    try:
+        model(*inputs)
+        torch.cuda.synchronize()
+    finally:
+        ops.lib.rf_gemm = orig
+    fams = {}
+    for s, e, fl, dt, M, N, K, nb, amode in recs:
+        if dt != 1:
+            fam = "gemm_f32_kernel (fp32 tiles)"
+        elif amode == 1:
+            fam = "gemm_bf16_kernel<conv3x3> (MFMA 16x16x32)"
+        else:
+            fam = "gemm_bf16_kernel (MFMA 16x16x32)"
+        f = fams.setdefault(fam, [0.0, 0.0, 0])
+        f[0] += s.elapsed_time(e) * 1e-3
+        f[1] += fl
+        f[2] += 1
+    return fams, sum(r[0].elapsed_time(r[1]) for r in recs) * 1e-3
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(cfg):
+    """Oracle timed on the host cores, bounded: ONE layer of each kind at the bench shapes with B=1 (every block
+    repeats the same layers), scaled by the layer counts of the full model."""
+    from oracle import rf_oracle as O
+    import rosettafold_pytorch_amd as R
+    mc, N, L = cfg["model"], cfg["N"], cfg["L"]
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    torch.manual_seed(1234)
+    small = dict(mc, n_two_track_blocks=1, n_three_track_blocks=2, n_encoder_layers=1, p_dropout=0.0)
+    model = R.RoseTTAFold(**small)
+    P = {k: v.detach().float() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    msa = torch.randn(1, N, L, mc["d_msa"], generator=g)
+    pair = torch.randn(1, L, L, mc["d_pair"], generator=g)
+    att = torch.rand(1, L, L, 12, generator=g)
+    seq = torch.randint(0, 21, (1, L), generator=g)
+    onehot = torch.nn.functional.one_hot(seq, 21).float()
+    aa = torch.arange(L).unsqueeze(0)
+    steps = torch.randn(1, L, 3, generator=g)  # protein-like CA trace: non-degenerate kNN graph / distance masks
+    ca = torch.cumsum(3.8 * steps / steps.norm(dim=-1, keepdim=True), 1)
+    xyz = ca[:, :, None, :] + 0.5 * torch.randn(1, L, 3, 3, generator=g)
+    state = torch.randn(1, L, mc["d_state"], generator=g)
+    tb, t3 = "two_track_blocks.0", "three_track_blocks.0"
+    pieces = {
+        "msa_row_layer": lambda: O.encoder_layer_tied(P, tb + ".msa_update_using_self_att.residue_wise_encoder_layers.0", msa, 12),
+        "msa_col_layer": lambda: O.encoder_layer_performer(P, tb + ".msa_update_using_self_att.sequence_wise_encoder_layers.0", msa.transpose(1, 2), 12),
+        "pair_update_with_msa": lambda: O.pair_update_with_msa(P, tb + ".pair_update_with_msa", msa, pair, att),
+        "pair_axial_layer": lambda: O.pair_axial_layer(P, tb + ".pair_update_with_axial_attention.layers.0", pair),
+        "msa_with_pair_layer": lambda: O.msa_update_with_pair_layer(P, tb + ".msa_update_with_pair.encoder_layers.0", msa, pair, 4),
+        "init_coord": lambda: O.initial_coord_generation(P, "initial_coord_generation_with_msa_and_pair", msa, pair, onehot, aa),
+        "coord_update": lambda: O.coord_update(P, t3 + ".coord_update_with_msa_and_pair", xyz, msa, pair, aa, onehot, mc["n_neighbors"][0], mc["d_state"]),
+        "msa_with_coord": lambda: O.msa_update_with_pair_and_coord(P, t3 + ".msa_update_with_pair_and_coord", xyz, state, msa),
+        "head": lambda: O.prediction_head(P, "prediction_head", pair),
+    }
+    t = {}
+    with torch.no_grad():
+        for name, fn in pieces.items():
+            t0 = time.perf_counter()
+            fn()
+            t[name] = time.perf_counter() - t0
+            log(f"cpu oracle {name}: {t[name]:.2f}s")
+    n2, n3, ne = mc["n_two_track_blocks"], mc["n_three_track_blocks"], mc["n_encoder_layers"]
+    nb = n2 + n3
+    full = (nb * (ne * (t["msa_row_layer"] + t["msa_col_layer"] + t["pair_axial_layer"] + t["msa_with_pair_layer"])
+                  + t["pair_update_with_msa"]) + t["init_coord"] + n3 * t["coord_update"] + (n3 - 1) * t["msa_with_coord"]
+            + t["head"])
+    return {"value": L / full, "unit": "residues/s", "cores": ncores, "kind": "port",
+            "sample": "B=1,N=%d,L=%d, one layer of each kind timed once (%s) = %.1fs of CPU work; scaled by the layer "
+                      "counts of the %d+%d-block model -> %.0fs/sample" % (
+                          N, L, ", ".join(f"{k} {v:.2f}s" for k, v in t.items()), sum(t.values()), n2, n3, full)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import rosettafold_pytorch_amd as R
+    cfg = CONFIGS[args.config]
+    R.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    torch.manual_seed(1234)  # identical weights on every rank
+    model = R.RoseTTAFold(p_dropout=0.0, **cfg["model"]).to(dev)
+    B, N, L = cfg["B"], cfg["N"], cfg["L"]
+    inputs = make_inputs(B, N, L, seed=rank, device=dev)  # independent MSAs per rank
+
+    def step():
+        logits, xyz, plddt = model(*inputs)
+        if world > 1:  # the one collective of the path: gather the results on rank 0 (RCCL over xGMI)
+            import torch.distributed as dist
+            flat = torch.cat([logits[k].reshape(-1) for k in ("theta", "phi", "dist", "omega")]
+                             + [xyz.reshape(-1), plddt.reshape(-1)])
+            bufs = [torch.empty_like(flat) for _ in range(world)] if rank == 0 else None
+            dist.gather(flat, bufs, dst=0)
+        return logits
+
+    def fence():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f"warmup step {i} done")
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        log(f"{args.steps} timed steps: {dt:.3f}s")
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+
+    if rank == 0:
+        out = {
+            "metric": "residues/sec forward (L=256, N=128)", "value": world * B * L * args.steps / dt,
+            "unit": "residues/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: bsz={B}/GPU, n_seq={N}, L={L}, "
+                                   f"d_msa={cfg['model']['d_msa']}, d_pair={cfg['model']['d_pair']}, "
+                                   f"{cfg['model']['n_two_track_blocks']}+{cfg['model']['n_three_track_blocks']} blocks, "
+                                   f"{cfg['model']['n_encoder_layers']} encoder layers, random-init weights",
+                       "global_batch": world * B, "parallelism": f"batch-sharded x{world} (replicated weights)"},
+        }
+        if world == 1 and not args.no_roofline:
+            fams, tot = profile_gemms(model, inputs)
+            name, (secs, flops, n) = max(fams.items(), key=lambda kv: kv[1][0])
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": flops / secs / 1e12,
+                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": flops / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "launches": n, "avg_launch_ms": 1e3 * secs / n,
+                               "algorithmic_gflop_per_launch": flops / n / 1e9,
+                               "share_of_step": secs / (dt / args.steps),
+                               "families": {k: {"s": v[0], "tflops": v[1] / max(v[0], 1e-12) / 1e12, "n": v[2]}
+                                            for k, v in fams.items()}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

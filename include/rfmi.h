@@ -101,14 +101,16 @@ int rf_softmax(const float* x, int64_t x_rs, int64_t x_cs, void* y, int y_dtype,
 int rf_tied_softmax(const float* logits, void* att, int att_dtype, float* att_sym, int64_t sym_ld, int B, int H,
                     int L, void* stream);
 
-/* PositionWiseWeightFactor core (rf.py:205-217): w[b,n,h,l] = softmax_n( sum_d q0[b,l,h,d]*k[b,n,l,h,d] ) with
- * q0 already scaled by the caller's projection (the d_head^-0.5 factor is `scale`).
- * q0: T [B,L,H*dh] (ld q0_ld); k: T [B,N,L,*] rows of ld k_ld, head h at column k_col0 + h*dh.
- * w (fp32 [B,N,H,L]) may be NULL.  When q_scale != NULL the kernel also does the fused
- * `q = q * w * qscale` of rf.py:252 in place on q_scale: T [B,N,L,*] (ld qs_ld, column qs_col0 + h*dh). */
-int rf_poswise(const void* q0, int64_t q0_ld, const void* k, int64_t k_ld, int k_col0, float* w, void* q_scale,
-               int64_t qs_ld, int qs_col0, int dtype, int B, int N, int L, int H, int dh, float scale, float qscale,
-               void* stream);
+/* PositionWiseWeightFactor core (rf.py:205-217): w[b,n,h,l] = softmax_n( scale * sum_{c<dlen} q0[b,l,h,c]*k[b,n,l,h,c] ).
+ * q0: [B,L,H*dlen] (dtype q0_dtype, ld q0_ld); k: T rows [B,N,L,*] of ld k_ld, head h at column k_col0 + h*k_hstride.
+ *   - direct form:    q0 = to_q(row 0), k = to_k(x), dlen = k_hstride = d_head;
+ *   - collapsed form: q0 = to_q(row 0) W_k (one [B*L,d]x[d,d] GEMM), k = x itself, dlen = d, k_hstride = 0
+ *     (the to_k GEMM over all N rows disappears; its bias is constant in n and drops out of the softmax).
+ * w (fp32 [B,N,H,L]) may be NULL.  When q_scale != NULL the kernel also does the fused `q = q * w * qscale` of
+ * rf.py:252 in place on q_scale: T [B,N,L,*] (ld qs_ld, head h = columns qs_col0 + h*qs_dh .. +qs_dh). */
+int rf_poswise(const void* q0, int q0_dtype, int64_t q0_ld, const void* k, int64_t k_ld, int k_col0, int k_hstride,
+               int dlen, float* w, void* q_scale, int64_t qs_ld, int qs_col0, int qs_dh, int dtype, int B, int N, int L,
+               int H, float scale, float qscale, void* stream);
 
 /* y[b,l,:] = sum_n w[b,n,0,l] * x[b,n,l,:]   (rf.py:723, rf.py:797); x T [B,N,L,D], y fp32 [B,L,D] (ld y_ld) */
 int rf_weighted_msa_sum(const void* x, int dtype, const float* w, float* y, int64_t y_ld, int B, int N, int L, int D,
@@ -139,6 +141,9 @@ int rf_copy4d(const void* x, int x_dtype, const int64_t xs[4], void* y, int y_dt
 /* y = a*x + b*z  elementwise fp32/T (n elements; z may be NULL) */
 int rf_axpby(const void* x, int x_dtype, float a, const void* z, int z_dtype, float b, void* y, int y_dtype,
              int64_t n, void* stream);
+
+/* x[r,:] *= w[r]  (msa_proj * position weight, rf.py:472); x T [rows, D] in place */
+int rf_scale_rows(void* x, int dtype, const float* w, int64_t rows, int D, void* stream);
 
 /* FAVOR+ softmax-kernel features (performer-pytorch softmax_kernel as called at rf.py:313-318; third party,
  * parity unpinned).  One workgroup per (sequence, head) S.  dash = (d^-1/4 x) P^T from rf_gemm, T, laid out
@@ -211,6 +216,9 @@ int rf_se3_gram(const float* v, float* s, int64_t V, int m, int deg, void* strea
 /* GAttentiveSelfInt back (ea/modules.py:458-471): y[v,o,:] = sum_m softmax_m(att[v,o,m]) * x[v,m,:]. */
 int rf_se3_attn_apply(const float* att, const float* x, float* y, int64_t V, int m_out, int m_in, int deg,
                       void* stream);
+
+/* type-1 SE(3) input (rf.py:807): y[r,a,:] = xyz[r,a,:] - xyz[r,CA,:] */
+int rf_center_ca(const float* xyz, float* y, int64_t nres, void* stream);
 
 /* Coordinate update (rf.py:816-819): xyz_out from xyz and displacement [B*L,3,3]. */
 int rf_coord_apply(const float* xyz, const float* disp, float* xyz_out, int64_t nres, void* stream);

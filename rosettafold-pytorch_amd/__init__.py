@@ -1,4 +1,9 @@
-"""rosettafold-pytorch_amd: MI355X-native RoseTTAFold forward path (HIP kernels behind the reference's
-nn.Module call surface).  Importing this package loads librfmi.so; it raises if the library is missing."""
+"""rosettafold-pytorch_amd: MI355X-native RoseTTAFold forward path (hand-written HIP kernels behind the
+reference's nn.Module call surface).  Importing this package loads librfmi.so and raises if it is missing:
+there is no CPU / PyTorch fallback."""
 from . import _lib  # noqa: F401  (fails loudly without the HIP library)
 from . import ops  # noqa: F401
+from .model import *  # noqa: F401,F403
+from .model import set_compute_dtype, RT  # noqa: F401
+from .structure import *  # noqa: F401,F403
+from .structure import flat_state  # noqa: F401

@@ -3,6 +3,8 @@ library is missing or a symbol is absent this module raises at import."""
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must be loaded first: librfmi.so binds to the HIP runtime torch already brought in
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librfmi.so")
 
@@ -40,7 +42,7 @@ PROTOTYPES = {
     "rf_sym_layernorm": [vp, vp, i32, i32, i32, i32, f32, vp],
     "rf_softmax": [vp, i64, i64, vp, i32, i64, i64, i32, f32, vp],
     "rf_tied_softmax": [vp, vp, i32, vp, i64, i32, i32, i32, vp],
-    "rf_poswise": [vp, i64, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp],
+    "rf_poswise": [vp, i32, i64, vp, i64, i32, i32, i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp],
     "rf_weighted_msa_sum": [vp, i32, vp, vp, i64, i32, i32, i32, i32, vp],
     "rf_instnorm_stats": [vp, i32, vp, i32, i64, i32, vp],
     "rf_instnorm_apply": [vp, i32, vp, vp, vp, f32, vp, i32, vp, i32, vp, i32, i32, i64, i32, vp],
@@ -62,6 +64,8 @@ PROTOTYPES = {
     "rf_se3_gram": [vp, vp, i64, i32, i32, vp],
     "rf_se3_attn_apply": [vp, vp, vp, i64, i32, i32, i32, vp],
     "rf_coord_apply": [vp, vp, vp, i64, vp],
+    "rf_center_ca": [vp, vp, i64, vp],
+    "rf_scale_rows": [vp, i32, vp, i64, i32, vp],
     "rf_version": [],
 }
 

@@ -170,19 +170,19 @@ extern "C" int rf_tied_softmax(const float* logits, void* att, int att_dtype, fl
 // ------------------------------------------------------------------------------------------------
 // PositionWiseWeightFactor core: block per (b,l); thread per (n,h) dot product; softmax over n
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void poswise_kernel(const void* q0, int64_t q0_ld, const void* k, int64_t k_ld,
-                                                      int k_col0, float* w, void* qs, int64_t qs_ld, int qs_col0,
-                                                      int dt, int B, int N, int L, int H, int dh, float scale,
-                                                      float qscale) {
+__global__ __launch_bounds__(256) void poswise_kernel(const void* q0, int q0_dt, int64_t q0_ld, const void* k,
+                                                      int64_t k_ld, int k_col0, int k_hs, int dlen, float* w, void* qs,
+                                                      int64_t qs_ld, int qs_col0, int qs_dh, int dt, int B, int N,
+                                                      int L, int H, float scale, float qscale) {
   extern __shared__ float sm[];  // logits [H][N]
   const int bl = blockIdx.x, b = bl / L, l = bl % L;
   const int NH = N * H;
   for (int e = threadIdx.x; e < NH; e += 256) {
     const int n = e / H, h = e % H;
-    const int64_t kb = (((int64_t)b * N + n) * L + l) * k_ld + k_col0 + h * dh;
-    const int64_t qb = ((int64_t)b * L + l) * q0_ld + h * dh;
+    const int64_t kb = (((int64_t)b * N + n) * L + l) * k_ld + k_col0 + h * k_hs;
+    const int64_t qb = ((int64_t)b * L + l) * q0_ld + h * dlen;
     float a = 0.f;
-    for (int c = 0; c < dh; ++c) a = fmaf(ld(q0, dt, qb + c), ld(k, dt, kb + c), a);
+    for (int c = 0; c < dlen; ++c) a = fmaf(ld(q0, q0_dt, qb + c), ld(k, dt, kb + c), a);
     sm[h * N + n] = a * scale;
   }
   __syncthreads();
@@ -202,21 +202,22 @@ __global__ __launch_bounds__(256) void poswise_kernel(const void* q0, int64_t q0
     const float wv_ = sm[h * N + n];
     if (w) w[(((int64_t)b * N + n) * H + h) * L + l] = wv_;
     if (qs) {
-      const int64_t o = (((int64_t)b * N + n) * L + l) * qs_ld + qs_col0 + h * dh;
+      const int64_t o = (((int64_t)b * N + n) * L + l) * qs_ld + qs_col0 + h * qs_dh;
       const float f = wv_ * qscale;
-      for (int c = 0; c < dh; ++c) st(qs, dt, o + c, ld(qs, dt, o + c) * f);
+      for (int c = 0; c < qs_dh; ++c) st(qs, dt, o + c, ld(qs, dt, o + c) * f);
     }
   }
 }
 
-extern "C" int rf_poswise(const void* q0, int64_t q0_ld, const void* k, int64_t k_ld, int k_col0, float* w,
-                          void* q_scale, int64_t qs_ld, int qs_col0, int dtype, int B, int N, int L, int H, int dh,
-                          float scale, float qscale, void* stream) {
+extern "C" int rf_poswise(const void* q0, int q0_dtype, int64_t q0_ld, const void* k, int64_t k_ld, int k_col0,
+                          int k_hstride, int dlen, float* w, void* q_scale, int64_t qs_ld, int qs_col0, int qs_dh,
+                          int dtype, int B, int N, int L, int H, float scale, float qscale, void* stream) {
   RF_CHECK_DT(dtype);
+  RF_CHECK_DT(q0_dtype);
   const size_t lds = (size_t)N * H * sizeof(float);
   if (lds > 64 * 1024) return RF_EINVAL;
-  hipLaunchKernelGGL(poswise_kernel, dim3(B * L), dim3(256), lds, (hipStream_t)stream, q0, q0_ld, k, k_ld, k_col0, w,
-                     q_scale, qs_ld, qs_col0, dtype, B, N, L, H, dh, scale, qscale);
+  hipLaunchKernelGGL(poswise_kernel, dim3(B * L), dim3(256), lds, (hipStream_t)stream, q0, q0_dtype, q0_ld, k, k_ld,
+                     k_col0, k_hstride, dlen, w, q_scale, qs_ld, qs_col0, qs_dh, dtype, B, N, L, H, scale, qscale);
   return rf_launch_status();
 }
 
@@ -614,6 +615,20 @@ extern "C" int rf_dist_masked_attention(const float* q, const float* k, const fl
   if (lds > 64 * 1024) return RF_EINVAL;
   hipLaunchKernelGGL(dist_att_kernel, dim3(B * L), dim3(256), lds, (hipStream_t)stream, q, k, xyz, bins, att, att_dtype,
                      L, H, dq);
+  return rf_launch_status();
+}
+
+// x[r, :] *= w[r]
+__global__ __launch_bounds__(256) void scale_rows_kernel(void* x, int dt, const float* w, int64_t total, int D) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
+    st(x, dt, e, ld(x, dt, e) * w[e / D]);
+}
+
+extern "C" int rf_scale_rows(void* x, int dtype, const float* w, int64_t rows, int D, void* stream) {
+  RF_CHECK_DT(dtype);
+  const int64_t total = rows * D;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(min(cdiv(total, 256), 32768u)), dim3(256), 0, (hipStream_t)stream, x,
+                     dtype, w, total, D);
   return rf_launch_status();
 }
 

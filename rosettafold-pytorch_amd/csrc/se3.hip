@@ -430,3 +430,17 @@ extern "C" int rf_coord_apply(const float* xyz, const float* disp, float* xyz_ou
                      xyz_out, nres);
   return rf_launch_status();
 }
+
+// type-1 input features (rf.py:807): y[r,a,:] = xyz[r,a,:] - xyz[r,CA,:]
+__global__ __launch_bounds__(256) void center_ca_kernel(const float* xyz, float* y, int64_t n) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int64_t r = e / 9;
+  const int c = e % 3;
+  y[e] = xyz[e] - xyz[(r * 3 + 1) * 3 + c];
+}
+
+extern "C" int rf_center_ca(const float* xyz, float* y, int64_t nres, void* stream) {
+  hipLaunchKernelGGL(center_ca_kernel, dim3(cdiv(nres * 9, 256)), dim3(256), 0, (hipStream_t)stream, xyz, y, nres * 9);
+  return rf_launch_status();
+}

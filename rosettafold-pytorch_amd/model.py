@@ -1,0 +1,941 @@
+"""RoseTTAFold forward path on MI355X: the reference's nn.Module call surface over librfmi.so.
+
+Class names, constructor arguments, `state_dict()` key names and forward signatures mirror
+rosettafold_pytorch/rosettafold_pytorch.py (cited per class as rf.py:LINE) so that a user of the
+reference can switch packages; the arithmetic inside every forward is a sequence of HIP kernels
+reached through the C ABI (include/rfmi.h).  PyTorch supplies device memory, the stream and the
+parameter containers (nn.Linear / nn.LayerNorm / ... are used for their weights and default init
+only -- their own forward is never called).
+
+Inference semantics: every dropout is the identity (the reference's unregistered layer lists
+ignore .eval(); here they are proper ModuleLists and their weights appear in
+state_dict under `...encoder_layers.N.` / `...blocks.N.`).
+
+Precision policy: the two residual streams (msa, pair) are fp32 in HBM; GEMM operands are the
+compute dtype (bf16 by default -> v_mfma_f32_16x16x32_bf16 with fp32 accumulation, or fp32 ->
+exact fp32 tiles for parity runs); LayerNorm / InstanceNorm / softmax statistics are fp32; the
+SE(3) structure module is fp32 end to end, as in the reference (se3_modules.py:164).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .ops import F32
+
+N_IDX, CA_IDX, C_IDX = 0, 1, 2  # rf.py:15
+M_FEAT = 266   # performer nb_features = int(64 * ln 64)
+M_PAD = 288    # padded to a multiple of 32 for the MFMA K loop
+VT_ROWS = 80   # 64 value rows + the ones row (k' sums) padded to a multiple of 16
+
+
+class _Runtime:
+    dtype = torch.bfloat16
+
+
+RT = _Runtime()
+
+
+def set_compute_dtype(dtype):
+    """torch.bfloat16 (MFMA path, default) or torch.float32 (exact fp32 path used for parity)."""
+    if dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("compute dtype must be bfloat16 or float32")
+    RT.dtype = dtype
+
+
+def T():
+    return RT.dtype
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+class RFModule(nn.Module):
+    """nn.Module with a cache of kernel-ready weights (cast / concatenated / padded)."""
+
+    def __init__(self):
+        super().__init__()
+        object.__setattr__(self, "_rfc", {})
+
+    def _apply(self, fn, *a, **k):
+        self._rfc.clear()
+        return super()._apply(fn, *a, **k)
+
+    def _load_from_state_dict(self, *a, **k):
+        self._rfc.clear()
+        return super()._load_from_state_dict(*a, **k)
+
+    def cached(self, key, fn):
+        k = (key, RT.dtype)
+        v = self._rfc.get(k)
+        if v is None:
+            with torch.no_grad():
+                v = fn()
+            self._rfc[k] = v
+        return v
+
+    # kernel-ready views of parameter containers -------------------------------------------------
+    def wt(self, key, lin, kpad=None):
+        def make():
+            w = lin.weight.detach().reshape(lin.weight.shape[0], -1)
+            if kpad is not None and kpad != w.shape[1]:
+                w = torch.cat([w, w.new_zeros(w.shape[0], kpad - w.shape[1])], 1)
+            return w.to(T()).contiguous()
+        return self.cached(("wt", key), make)
+
+    def wcat(self, key, lins):
+        return self.cached(("wcat", key), lambda: torch.cat([l.weight.detach() for l in lins], 0).to(T()).contiguous())
+
+    def bcat(self, key, lins):
+        return self.cached(("bcat", key), lambda: torch.cat([l.bias.detach() for l in lins], 0).float().contiguous())
+
+
+def _f(p):
+    return None if p is None else p.detach()
+
+
+def ln(mod, x, out_dtype=None, **kw):
+    return ops.layernorm(x, _f(mod.weight), _f(mod.bias), eps=mod.eps, out_dtype=out_dtype or T(), **kw)
+
+
+# ================================================================================================
+# small building blocks
+# ================================================================================================
+class Residual(nn.Module):
+    """rf.py:18-28 -- parameter container only (keeps the reference's `fn` naming)."""
+
+    def __init__(self, fn, p_dropout=None):
+        super().__init__()
+        self.fn = fn
+
+
+class FeedForward(RFModule):
+    """rf.py:270-281."""
+
+    def __init__(self, d_emb, d_ff, p_dropout=0.1):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(d_emb, d_ff), nn.ReLU(), nn.Dropout(p_dropout), nn.Linear(d_ff, d_emb))
+
+    def apply_residual(self, xn, x_res):
+        """x_res += W2 relu(W1 xn + b1) + b2   (x_res fp32, in place)."""
+        h = ops.linear(xn, self.wt("w1", self.net[0]), _f(self.net[0].bias), act=L.ACT_RELU)
+        ops.linear(h, self.wt("w2", self.net[3]), _f(self.net[3].bias), out=x_res, residual=x_res)
+        return x_res
+
+    def forward(self, x):
+        xn = ops.cast(x.contiguous(), T())
+        out = torch.zeros(x.shape, device=x.device, dtype=F32)
+        return self.apply_residual(xn, out)
+
+
+def sinusoid_table(dim, max_len):
+    """rf.py:63-68 (host-side constant table)."""
+    pe = torch.zeros(max_len, dim)
+    denom = torch.exp(math.log(10000.0) * torch.arange(0, dim, 2) / dim)
+    pos = torch.arange(0, max_len).view(-1, 1)
+    pe[:, 0::2] = torch.sin(pos / denom)
+    pe[:, 1::2] = torch.cos(pos / denom)
+    return pe
+
+
+class SinusoidalPositionalEncoding(RFModule):
+    """rf.py:57-76."""
+
+    def __init__(self, dim, max_len, p_dropout=0.1):
+        super().__init__()
+        self.dim, self.max_len = dim, max_len
+        self.register_buffer("pos_enc", sinusoid_table(dim, max_len), persistent=False)
+
+
+class SinusoidalPositionalEncoding2D(RFModule):
+    """rf.py:79-103."""
+
+    def __init__(self, dim, max_len, p_dropout=0.1):
+        super().__init__()
+        self.max_len = max_len
+        self.register_buffer("pos_enc", sinusoid_table(dim // 2, max_len), persistent=False)
+
+
+class MsaEmbedding(RFModule):
+    """rf.py:106-120."""
+
+    def __init__(self, d_input=21, d_msa=384, max_len=260, p_pe_drop=0.1):
+        super().__init__()
+        self.to_embedding = nn.Embedding(d_input, d_msa)
+        self.pos_enc = SinusoidalPositionalEncoding(d_msa, max_len, p_pe_drop)
+        self.query_enc = nn.Embedding(2, d_msa)
+
+    def forward(self, x, aa_idx):
+        return ops.msa_embed(x.contiguous(), aa_idx.contiguous(), _f(self.to_embedding.weight), self.pos_enc.pos_enc,
+                             _f(self.query_enc.weight))
+
+
+class PairEmbedding(RFModule):
+    """rf.py:123-181 (use_template=False path; the 289->d_pair Linear is folded into two 21-row tables)."""
+
+    def __init__(self, d_input=21, d_pair=288, max_len=260, p_pe_drop=0.1, use_template=False, d_template=64):
+        super().__init__()
+        self.half_d_pair = d_pair // 2
+        self.embed_seq = nn.Embedding(d_input, self.half_d_pair)
+        self.pos_enc = SinusoidalPositionalEncoding2D(d_pair, max_len, p_pe_drop)
+        self.use_template = use_template
+        if use_template:
+            raise NotImplementedError("template branch (rf.py:141-169) is outside the forward path (SURVEY 8(f))")
+        self.proj = nn.Linear(d_pair + 1, d_pair)
+
+    def forward(self, seq, aa_idx, template=None):
+        if template is not None:
+            raise ValueError(f"[{self.__class__.__name__}]: template is not None but use_template is False")
+        h = self.half_d_pair
+
+        def tables():
+            e = self.embed_seq.weight.detach().float().contiguous()
+            w = self.proj.weight.detach().float()
+            tl = ops.linear(e, w[:, :h].contiguous(), None)
+            tr = ops.linear(e, w[:, h:2 * h].contiguous(), None)
+            return tl, tr, w[:, 2 * h].contiguous()
+
+        tl, tr, wsep = self.cached("tables", tables)
+        return ops.pair_embed(seq.contiguous(), aa_idx.contiguous(), tl, tr, wsep, _f(self.proj.bias), self.pos_enc.pos_enc)
+
+
+# ================================================================================================
+# MSA row (tied) attention
+# ================================================================================================
+class PositionWiseWeightFactor(RFModule):
+    """rf.py:184-217."""
+
+    def __init__(self, d_msa=384, n_heads=12, p_dropout=0.1):
+        super().__init__()
+        assert d_msa % n_heads == 0, \
+            f"[{self.__class__.__name__}]: d_msa ({d_msa}) must be divisible by n_heads ({n_heads})."
+        self.n_heads = n_heads
+        self.d_head = d_msa // n_heads
+        self.scale = self.d_head ** (-0.5)
+        self.to_q = nn.Sequential(nn.Linear(d_msa, d_msa), nn.Identity())
+        self.to_k = nn.Sequential(nn.Linear(d_msa, d_msa), nn.Identity())
+
+    def query_proj(self, xn):
+        """to_q on MSA row 0 only: [B*L, d] (T)."""
+        B, N, Lr, D = xn.shape
+        q0 = torch.empty(B * Lr, D, device=xn.device, dtype=T())
+        ops.gemm(xn, self.wt("q", self.to_q[0]), q0, B * Lr, D, D, a_row=(Lr, N * Lr * D, D),
+                 bias=_f(self.to_q[0].bias))
+        return q0
+
+    def weights(self, xn, w_out=None):
+        """xn: T [B,N,L,d] -> w fp32 [B,N,H,L]."""
+        B, N, Lr, D = xn.shape
+        q0 = self.query_proj(xn)
+        k = ops.linear(xn, self.wt("k", self.to_k[0]), _f(self.to_k[0].bias))
+        w = torch.empty(B, N, self.n_heads, Lr, device=xn.device, dtype=F32) if w_out is None else w_out
+        ops.poswise(q0, D, k, D, 0, self.d_head, self.d_head, w, None, 0, 0, 0, B, N, Lr, self.n_heads, self.scale, 1.0)
+        return w
+
+    def weights_collapsed(self, msa, lnm, m):
+        """1-head weights for the structure track, q side in fp32: w = softmax_n(scale * m[b,n,l,:] . u[b,l,:]) with
+        u = to_q(LN(msa[:,0])) W_k  (to_k's bias is constant over n and drops out of the softmax).
+        msa fp32 [B,N,L,D]; lnm = the LayerNorm applied to it; m = lnm(msa) in T."""
+        assert self.n_heads == 1
+        B, N, Lr, D = msa.shape
+        row0 = ops.layernorm(msa[:, 0].contiguous(), _f(lnm.weight), _f(lnm.bias), eps=lnm.eps, out_dtype=F32)
+        q0 = ops.linear(row0, self.to_q[0].weight.detach().float(), _f(self.to_q[0].bias), out_dtype=F32)
+        wkt = self.cached("wkt32", lambda: self.to_k[0].weight.detach().float().t().contiguous())
+        u = ops.linear(q0, wkt, None, out_dtype=F32)
+        w = torch.empty(B, N, 1, Lr, device=msa.device, dtype=F32)
+        ops.poswise(u, D, m, D, 0, 0, D, w, None, 0, 0, 0, B, N, Lr, 1, self.scale, 1.0)
+        return w
+
+    def forward(self, msa_emb):
+        w = self.weights(ops.cast(msa_emb.contiguous(), T()))
+        return w.unsqueeze(-1)  # b N h l 1
+
+
+class SoftTiedAttentionOverResidues(RFModule):
+    """rf.py:220-267."""
+
+    def __init__(self, d_msa=384, n_heads=12, p_dropout=0.1, return_att=False):
+        super().__init__()
+        assert d_msa % n_heads == 0, \
+            f"[{self.__class__.__name__}]: d_msa ({d_msa}) must be divisible by n_heads ({n_heads})."
+        self.n_heads, self.d_head = n_heads, d_msa // n_heads
+        self.scale = self.d_head ** (-0.5)
+        self.return_att = return_att
+        self.poswise_weight = PositionWiseWeightFactor(d_msa, n_heads, p_dropout)
+        self.to_q = nn.Linear(d_msa, d_msa)
+        self.to_k = nn.Linear(d_msa, d_msa)
+        self.to_v = nn.Linear(d_msa, d_msa)
+        self.to_out = nn.Linear(d_msa, d_msa)
+
+    def attend(self, xn, x_res, want_att):
+        """xn: T [B,N,L,D] (already layer-normed); x_res: fp32 [B,N,L,D] += to_out(attention).  Returns the
+        symmetrised attention map fp32 [B,L,L,H] when want_att."""
+        B, N, Lr, D = xn.shape
+        H, dh = self.n_heads, self.d_head
+        dev = xn.device
+        pw = self.poswise_weight
+        # one GEMM for q | k | poswise-k  (N = 3D)
+        wcat = self.wcat("qkp", [self.to_q, self.to_k, pw.to_k[0]])
+        bcat = self.bcat("qkp", [self.to_q, self.to_k, pw.to_k[0]])
+        qkp = ops.linear(xn, wcat, bcat)  # [B,N,L,3D]
+        q0 = pw.query_proj(xn)
+        # w = softmax_n(q0.k_pw * scale);  q <- q * w * scale   (rf.py:252)
+        ops.poswise(q0, D, qkp, 3 * D, 2 * D, dh, dh, None, qkp, 3 * D, 0, dh, B, N, Lr, H, pw.scale, self.scale)
+        # v transposed: v_t[b,n,(h,d),l]
+        v_t = torch.empty(B, N, D, Lr, device=dev, dtype=T())
+        ops.gemm(self.wt("v", self.to_v), xn, v_t, D, Lr, D, batch=(B * N, 1, 1), b_bs=(Lr * D, 0, 0),
+                 c_bs=(D * Lr, 0, 0), c_row=(0, 0, Lr), bias=_f(self.to_v.bias), bias_mode=L.BIAS_ROW)
+        # logits[b,h,i,j] = sum_{n,d} q k   (contraction over N*dh, rf.py:254)
+        logits = torch.empty(B, H, Lr, Lr, device=dev, dtype=F32)
+        W3 = 3 * D
+        ops.gemm(qkp, qkp, logits, Lr, Lr, N * dh, batch=(B, H, 1), b_off=D,
+                 a_bs=(N * Lr * W3, dh, 0), a_row=(0, 0, W3), a_ko=Lr * W3,
+                 b_bs=(N * Lr * W3, dh, 0), b_row=(0, 0, W3), b_ko=Lr * W3, kc=dh,
+                 c_bs=(H * Lr * Lr, Lr * Lr, 0), c_row=(0, 0, Lr))
+        att = torch.empty(B, H, Lr, Lr, device=dev, dtype=T())
+        att_sym = torch.empty(B, Lr, Lr, H, device=dev, dtype=F32) if want_att else None
+        ops.tied_softmax(logits, att, att_sym, H)
+        # out[b,n,i,(h,d)] = sum_j att[b,h,i,j] v[b,n,h,j,d]   (rf.py:257-258)
+        out = torch.empty(B, N, Lr, D, device=dev, dtype=T())
+        ops.gemm(att, v_t, out, Lr, N * dh, Lr, batch=(B, H, 1),
+                 a_bs=(H * Lr * Lr, Lr * Lr, 0), a_row=(0, 0, Lr),
+                 b_bs=(N * D * Lr, dh * Lr, 0), b_row=(dh, D * Lr, Lr),
+                 c_bs=(N * Lr * D, dh, 0), c_row=(0, 0, D), c_col=(dh, Lr * D))
+        ops.linear(out, self.wt("o", self.to_out), _f(self.to_out.bias), out=x_res, residual=x_res)
+        return att_sym
+
+    def forward(self, x):
+        xn = ops.cast(x.contiguous(), T())
+        out = torch.zeros(x.shape, device=x.device, dtype=F32)
+        att = self.attend(xn, out, self.return_att)
+        return (out, att) if self.return_att else out
+
+
+# ================================================================================================
+# Performer (FAVOR+) self attention -- restated third-party module (parity unpinned)
+# ================================================================================================
+class _FastAttention(nn.Module):
+    def __init__(self, dim_heads, nb_features):
+        super().__init__()
+        self.register_buffer("projection_matrix", gaussian_orthogonal_random_matrix(nb_features, dim_heads))
+
+
+def gaussian_orthogonal_random_matrix(nb_rows, nb_cols, generator=None):
+    """performer-pytorch's projection construction (scaling=0); see oracle for the citation."""
+    blocks = []
+    for _ in range(nb_rows // nb_cols):
+        q, _ = torch.linalg.qr(torch.randn(nb_cols, nb_cols, generator=generator), mode="reduced")
+        blocks.append(q.t())
+    rem = nb_rows - (nb_rows // nb_cols) * nb_cols
+    if rem > 0:
+        q, _ = torch.linalg.qr(torch.randn(nb_cols, nb_cols, generator=generator), mode="reduced")
+        blocks.append(q.t()[:rem])
+    mat = torch.cat(blocks)
+    mult = torch.randn(nb_rows, nb_cols, generator=generator).norm(dim=1)
+    return torch.diag(mult) @ mat
+
+
+class PerformerSelfAttention(RFModule):
+    """performer_pytorch.SelfAttention as the reference instantiates it (rf.py:313-318, 505-518):
+    dim_head=64, nb_features=266, no qkv bias, output bias; softmax-kernel or generalized ReLU features."""
+
+    def __init__(self, dim, heads=8, dim_head=64, dropout=0.0, generalized_attention=False, **kw):
+        super().__init__()
+        inner = dim_head * heads
+        self.heads, self.dim_head, self.inner = heads, dim_head, inner
+        self.generalized = generalized_attention
+        self.fast_attention = _FastAttention(dim_head, int(dim_head * math.log(dim_head)))
+        self.to_q = nn.Linear(dim, inner, bias=False)
+        self.to_k = nn.Linear(dim, inner, bias=False)
+        self.to_v = nn.Linear(dim, inner, bias=False)
+        self.to_out = nn.Linear(inner, dim)
+
+    def proj_scaled(self):
+        def make():
+            p = self.fast_attention.projection_matrix.detach().float() * self.dim_head ** -0.25
+            pp = p.new_zeros(M_PAD, self.dim_head)
+            pp[: p.shape[0]] = p
+            return pp.to(T()).contiguous()
+        return self.cached("proj", make)
+
+    def attend(self, xn, x_res, axis):
+        """xn: T [B,L1,L2,D] layer-normed input; sequences run along `axis` (1 or 2); x_res (fp32, same shape)
+        += to_out(linear attention).  All intermediates are addressed by strides: no transposes."""
+        B, L1, L2, D = xn.shape
+        H, dh, inner = self.heads, self.dim_head, self.inner
+        dev = xn.device
+        Ls, Lo = (L1, L2) if axis == 1 else (L2, L1)
+        ss, so = (L2, 1) if axis == 1 else (1, L2)  # row strides of the sequence / outer index
+        RB = L1 * L2
+        R = B * RB
+        W2 = 2 * inner
+        S = B * Lo * H
+        m = self.fast_attention.projection_matrix.shape[0]
+        pc = self.proj_scaled()
+        gen = self.generalized
+        qk = ops.linear(xn, self.wcat("qk", [self.to_q, self.to_k]), None)  # [R, 2*inner]
+        # q' [B,Lo,H,Ls,M_PAD]
+        dq = torch.empty(B, Lo, H, Ls, M_PAD, device=dev, dtype=T())
+        ops.gemm(qk, pc, dq, Ls * H, M_PAD, dh, batch=(B, Lo, 1),
+                 a_bs=(RB * W2, so * W2, 0), a_row=(H, ss * W2, dh),
+                 c_bs=(Lo * H * Ls * M_PAD, H * Ls * M_PAD, 0), c_row=(H, M_PAD, Ls * M_PAD),
+                 act=L.ACT_RELU_EPS if gen else L.ACT_NONE, act_nvalid=m, act_eps=1e-3)
+        # k'^T [B,Lo,H,M_PAD,Ls]
+        kt = torch.empty(B, Lo, H, M_PAD, Ls, device=dev, dtype=T())
+        ops.gemm(pc, qk, kt, M_PAD, Ls, dh, batch=(B, Lo, H), b_off=inner,
+                 b_bs=(RB * W2, so * W2, dh), b_row=(0, 0, ss * W2),
+                 c_bs=(Lo * H * M_PAD * Ls, H * M_PAD * Ls, M_PAD * Ls), c_row=(0, 0, Ls),
+                 act=L.ACT_RELU_EPS if gen else L.ACT_NONE, act_nvalid=-m, act_eps=1e-3)
+        if not gen:
+            xs = (RB * W2, so * W2, dh, ss * W2)
+            ops.favor_softmax_features(dq, qk, 0, xs, Lo, H, S, Ls, m, M_PAD, dh, 1, 0)
+            ops.favor_softmax_features(kt, qk, inner, xs, Lo, H, S, Ls, m, M_PAD, dh, 0, 1)
+        # v^T [B,Lo,H,80,Ls] with a ones row at index 64 (-> k' column sums ride along in the context GEMM)
+        vt = torch.zeros(B, Lo, H, VT_ROWS, Ls, device=dev, dtype=T())
+        vt[:, :, :, dh] = 1
+        ops.gemm(self.wt("v", self.to_v), xn, vt, inner, Ls, D, batch=(B, Lo, 1),
+                 b_bs=(RB * D, so * D, 0), b_row=(0, 0, ss * D),
+                 c_bs=(Lo * H * VT_ROWS * Ls, H * VT_ROWS * Ls, 0), c_row=(dh, VT_ROWS * Ls, Ls))
+        # context^T [S,80,M_PAD] = v^T k'
+        ctx = torch.empty(S, VT_ROWS, M_PAD, device=dev, dtype=T())
+        ops.gemm(vt, kt, ctx, VT_ROWS, M_PAD, Ls, batch=(S, 1, 1), a_bs=(VT_ROWS * Ls, 0, 0),
+                 b_bs=(M_PAD * Ls, 0, 0), c_bs=(VT_ROWS * M_PAD, 0, 0))
+        # numerator | denominator: num[b,p1,p2,h,0:64 | 64]
+        num = torch.empty(R * H, VT_ROWS, device=dev, dtype=F32)
+        ops.gemm(dq, ctx, num, Ls, VT_ROWS, M_PAD, batch=(B, Lo, H),
+                 a_bs=(Lo * H * Ls * M_PAD, H * Ls * M_PAD, Ls * M_PAD), a_row=(0, 0, M_PAD),
+                 b_bs=(Lo * H * VT_ROWS * M_PAD, H * VT_ROWS * M_PAD, VT_ROWS * M_PAD),
+                 c_bs=(RB * H * VT_ROWS, so * H * VT_ROWS, VT_ROWS), c_row=(0, 0, ss * H * VT_ROWS))
+        o = torch.empty(R, inner, device=dev, dtype=T())
+        ops.linattn_normalize(num, VT_ROWS, o, dh, R * H, dh)
+        ops.linear(o, self.wt("o", self.to_out), _f(self.to_out.bias), out=x_res, residual=x_res)
+
+    def forward(self, x):
+        """x [S, n, dim] -> [S, n, dim] (library call surface)."""
+        S_, n, D = x.shape
+        xn = ops.cast(x.contiguous(), T()).view(1, S_, n, D)
+        out = torch.zeros(1, S_, n, D, device=x.device, dtype=F32)
+        self.attend(xn, out, axis=2)
+        return out.view(S_, n, D)
+
+
+# ================================================================================================
+# encoder layers / MSA self attention update
+# ================================================================================================
+class EncoderLayer(RFModule):
+    """rf.py:284-354."""
+
+    def __init__(self, d_msa=384, d_ff=384 * 4, n_heads=12, p_dropout=0.1, tied=False, performer=False,
+                 performer_kws={}, return_att=False):
+        super().__init__()
+        self.tied, self.return_att = tied, return_att
+        if tied:
+            self.attn = SoftTiedAttentionOverResidues(d_msa=d_msa, n_heads=n_heads, p_dropout=p_dropout,
+                                                      return_att=return_att)
+        elif performer:
+            if return_att:
+                raise NotImplementedError("PerformerSelfAttention does not support return_att.")
+            self.attn = PerformerSelfAttention(dim=d_msa, heads=n_heads, dropout=p_dropout, **performer_kws)
+        else:
+            raise NotImplementedError
+        self.ln = nn.LayerNorm(d_msa)
+        self.ff = Residual(nn.Sequential(nn.LayerNorm(d_msa), FeedForward(d_msa, d_ff, p_dropout=p_dropout),
+                                         nn.Dropout(p_dropout)))
+
+    def run(self, x, seq_axis=2, want_att=False):
+        """x: fp32 residual stream [B,n1,n2,D], updated in place.  tied: rows = n1 (MSA depth), attention over n2.
+        performer: attention along `seq_axis`."""
+        xn = ln(self.ln, x)
+        att = None
+        if self.tied:
+            att = self.attn.attend(xn, x, want_att)
+        else:
+            self.attn.attend(xn, x, seq_axis)
+        self.ff.fn[1].apply_residual(ln(self.ff.fn[0], x), x)
+        return att
+
+    def forward(self, x):
+        x = x.detach().float().clone().contiguous()
+        if self.tied:
+            att = self.run(x, want_att=self.return_att)
+            return (x, att) if self.return_att else x
+        # reference flattens (b n) l d: attention along dim 2 of [b, n, l, d]
+        self.run(x, seq_axis=2)
+        return x
+
+
+class MsaUpdateUsingSelfAttention(RFModule):
+    """rf.py:357-409."""
+
+    def __init__(self, d_msa=384, d_ff=384 * 4, n_heads=12, p_dropout=0.1, n_encoder_layers=4, performer_kws={}):
+        super().__init__()
+        self.residue_wise_encoder_layers = nn.ModuleList([
+            EncoderLayer(d_msa=d_msa, d_ff=d_ff, n_heads=n_heads, p_dropout=p_dropout, tied=True, performer=False,
+                         return_att=True) for _ in range(n_encoder_layers)])
+        self.sequence_wise_encoder_layers = nn.ModuleList([
+            EncoderLayer(d_msa=d_msa, d_ff=d_ff, n_heads=n_heads, p_dropout=p_dropout, tied=False, performer=True,
+                         performer_kws=performer_kws) for _ in range(n_encoder_layers)])
+
+    def run(self, x):
+        att = None
+        n = len(self.residue_wise_encoder_layers)
+        for i, layer in enumerate(self.residue_wise_encoder_layers):
+            a = layer.run(x, want_att=(i == n - 1))  # only the last layer's map is consumed (rf.py:400-401)
+            att = a if a is not None else att
+        for layer in self.sequence_wise_encoder_layers:
+            layer.run(x, seq_axis=1)  # the reference transposes to b l n d: sequences run over the MSA depth
+        return att
+
+    def forward(self, x):
+        x = x.detach().float().clone().contiguous()
+        return x, self.run(x)
+
+
+# ================================================================================================
+# pair update with MSA (outer product + 2-conv ResNet)
+# ================================================================================================
+class OuterProductMean(RFModule):
+    """rf.py:412-427."""
+
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.to_out = nn.Sequential(nn.LayerNorm(in_features ** 2), nn.Linear(in_features ** 2, out_features))
+
+    def run(self, x_t, y_t, N):
+        """x_t, y_t: T [B, L, P, N] (MSA depth contiguous).  -> fp32 [B,L,L,out]"""
+        B, Lr, P, _ = x_t.shape
+        PP = P * P
+        co = torch.empty(B, Lr, Lr, PP, device=x_t.device, dtype=T())
+        ops.gemm(x_t, y_t, co, Lr * P, Lr * P, N, batch=(B, 1, 1), a_bs=(Lr * P * N, 0, 0), b_bs=(Lr * P * N, 0, 0),
+                 c_bs=(Lr * Lr * PP, 0, 0), c_row=(P, Lr * PP, P), c_col=(P, PP))
+        cn = ln(self.to_out[0], co)
+        return ops.linear(cn, self.wt("w", self.to_out[1]), _f(self.to_out[1].bias), out_dtype=F32)
+
+    def forward(self, x, y=None):
+        y = x if y is None else y
+        B, N, Lr, P = x.shape
+        Np = pad8(N)
+        xt = torch.zeros(B, Lr, P, Np, device=x.device, dtype=T())
+        yt = torch.zeros(B, Lr, P, Np, device=x.device, dtype=T())
+        for src, dst in ((x, xt), (y, yt)):
+            ops.copy4d(src.contiguous(), (N * Lr * P, P, 1, Lr * P), dst, (Lr * P * Np, P * Np, Np, 1), (B, Lr, P, N))
+        return self.run(xt, yt, Np)
+
+
+class PairUpdateWithMsa(RFModule):
+    """rf.py:430-498."""
+
+    def __init__(self, d_msa, d_proj, d_pair, n_heads, p_dropout=0.1):
+        super().__init__()
+        self.d_proj, self.d_pair, self.n_heads = d_proj, d_pair, n_heads
+        self.proj_msa = nn.Sequential(nn.LayerNorm(d_msa), nn.Linear(d_msa, d_proj), nn.LayerNorm(d_proj))
+        self.poswise_weight = PositionWiseWeightFactor(d_proj, 1, p_dropout)
+        self.outer_product_mean = OuterProductMean(d_proj, d_pair)
+        self.ln_coevol_feat = nn.LayerNorm(d_pair)
+        self.ln_pair = nn.LayerNorm(d_pair)
+        d_feat_full = d_pair * 2 + d_proj * 4 + n_heads
+        self.d_feat = d_feat_full
+        self.resnet = nn.Sequential(
+            nn.Linear(d_feat_full, d_pair),
+            Residual(nn.Sequential(
+                nn.Identity(),
+                nn.Conv2d(d_pair, d_pair, kernel_size=3, padding="same", bias=False),
+                nn.InstanceNorm2d(d_pair, affine=True, eps=1e-6),
+                nn.ELU(),
+                nn.Dropout(p_dropout),
+                nn.Conv2d(d_pair, d_pair, kernel_size=3, padding="same", bias=False),
+                nn.InstanceNorm2d(d_pair, affine=True, eps=1e-6),
+                nn.Identity(),
+            )),
+            nn.ELU(),
+        )
+
+    def run(self, msa, pair, att):
+        """msa fp32 [B,N,L,D], pair fp32 [B,L,L,Dp], att fp32 [B,L,L,H] -> new pair fp32."""
+        B, N, Lr, D = msa.shape
+        P, Dp = self.d_proj, self.d_pair
+        dev = msa.device
+        Np = pad8(N)
+        mp_pre = ops.linear(ln(self.proj_msa[0], msa), self.wt("p", self.proj_msa[1]), _f(self.proj_msa[1].bias),
+                            out_dtype=F32)
+        mp = ln(self.proj_msa[2], mp_pre)  # T [B,N,L,P]
+        w = self.poswise_weight.weights(mp)  # fp32 [B,N,1,L]
+        # 1-D features: sum over N and the query row
+        msa1d = torch.empty(B, Lr, 2 * P, device=dev, dtype=F32)
+        ones = self.cached(("ones", B, N, Lr), lambda: torch.ones(B, N, 1, Lr, device=dev, dtype=F32))
+        ops.weighted_msa_sum(mp, ones, msa1d, 2 * P)
+        ops.copy4d(mp, (N * Lr * P, 0, P, 1), msa1d, (Lr * 2 * P, 0, 2 * P, 1), (B, 1, Lr, P), y_off=P)
+        # transposed operands of the outer product: x_t[b,i,u,n] = mp ; y_t = mp * w   (rf.py:472-473)
+        mpw = ops.scale_rows(mp.clone(), w, B * N * Lr, P)
+        xt = torch.zeros(B, Lr, P, Np, device=dev, dtype=T())
+        yt = torch.zeros(B, Lr, P, Np, device=dev, dtype=T())
+        for src, dst in ((mp, xt), (mpw, yt)):
+            ops.copy4d(src, (N * Lr * P, P, 1, Lr * P), dst, (Lr * P * Np, P * Np, Np, 1), (B, Lr, P, N))
+        coevol = self.outer_product_mean.run(xt, yt, Np)  # fp32 [B,L,L,Dp]
+        # feature tensor (K padded to a multiple of 8)
+        Kf = pad8(self.d_feat)
+        feat = torch.zeros(B, Lr, Lr, Kf, device=dev, dtype=T())
+        ln(self.ln_coevol_feat, coevol, out=feat, out_ld=Kf, out_off=0)
+        ops.tile_1d_feats(msa1d, feat, Kf, Dp, B, Lr, 2 * P)
+        ln(self.ln_pair, pair, out=feat, out_ld=Kf, out_off=Dp + 4 * P)
+        H = att.shape[-1]
+        ops.copy4d(att.contiguous(), (0, 0, H, 1), feat, (0, 0, Kf, 1), (1, 1, B * Lr * Lr, H), y_off=2 * Dp + 4 * P)
+        x = ops.linear(feat, self.wt("f", self.resnet[0], kpad=Kf), _f(self.resnet[0].bias), out_dtype=F32)
+        blk = self.resnet[1].fn
+        y = conv3x3(self, "c1", blk[1], ops.cast(x, T()), 1)
+        y, _ = ops.instnorm(y, _f(blk[2].weight), _f(blk[2].bias), eps=blk[2].eps, act=L.ACT_ELU, out_dtype=T())
+        y = conv3x3(self, "c2", blk[5], y, 1)
+        out, _ = ops.instnorm(y, _f(blk[6].weight), _f(blk[6].bias), eps=blk[6].eps, residual=x, act=L.ACT_ELU,
+                              out_dtype=F32)
+        return out
+
+    def forward(self, msa, pair, att):
+        return self.run(msa.float().contiguous(), pair.float().contiguous(), att.float().contiguous())
+
+
+def conv3x3(mod, key, conv, x, dilation, out_dtype=None):
+    """3x3 'same' convolution on NHWC x (T) as implicit GEMM (rf.py:452,456; resnet.py:19-38)."""
+    B, Hh, Ww, Cc = x.shape
+    Co = conv.weight.shape[0]
+    wk = mod.cached(("conv", key), lambda: conv.weight.detach().permute(0, 2, 3, 1).reshape(Co, 9 * Cc).to(T()).contiguous())
+    out = torch.empty(B, Hh, Ww, Co, device=x.device, dtype=out_dtype or T())
+    ops.gemm(x, wk, out, B * Hh * Ww, Co, 9 * Cc, conv=(B, Hh, Ww, Cc, dilation),
+             bias=_f(conv.bias) if conv.bias is not None else None)
+    return out
+
+
+# ================================================================================================
+# pair axial attention
+# ================================================================================================
+class PairUpdateWithAxialAttentionLayer(RFModule):
+    """rf.py:501-528.  RowWise: sequences along dim 1 (i) for fixed j; ColWise: along dim 2 (rf.py:31-54)."""
+
+    def __init__(self, d_pair, d_ff, n_heads, p_dropout, performer_kws):
+        super().__init__()
+        self.row_attn = PerformerSelfAttention(dim=d_pair, heads=n_heads, dropout=p_dropout,
+                                               generalized_attention=True, **performer_kws)
+        self.col_attn = PerformerSelfAttention(dim=d_pair, heads=n_heads, dropout=p_dropout,
+                                               generalized_attention=True, **performer_kws)
+        self.ff = FeedForward(d_pair, d_ff, p_dropout)
+        # same aliasing as the reference: layer.k.fn.0 = LayerNorm, layer.0.fn.1.fn = row_attn, ...
+        self.layer = nn.Sequential(
+            Residual(nn.Sequential(nn.LayerNorm(d_pair), Residual(self.row_attn))),
+            Residual(nn.Sequential(nn.LayerNorm(d_pair), Residual(self.col_attn))),
+            Residual(nn.Sequential(nn.LayerNorm(d_pair), self.ff)),
+        )
+
+    def run(self, x):
+        self.row_attn.attend(ln(self.layer[0].fn[0], x), x, axis=1)
+        self.col_attn.attend(ln(self.layer[1].fn[0], x), x, axis=2)
+        self.ff.apply_residual(ln(self.layer[2].fn[0], x), x)
+
+    def forward(self, x):
+        x = x.detach().float().clone().contiguous()
+        self.run(x)
+        return x
+
+
+class PairUpdateWithAxialAttention(RFModule):
+    """rf.py:531-547."""
+
+    def __init__(self, d_pair, d_ff, n_heads, p_dropout, n_encoder_layers, performer_kws={}):
+        super().__init__()
+        self.layers = nn.ModuleList([PairUpdateWithAxialAttentionLayer(d_pair, d_ff, n_heads, p_dropout, performer_kws)
+                                     for _ in range(n_encoder_layers)])
+
+    def run(self, x):
+        for layer in self.layers:
+            layer.run(x)
+
+    def forward(self, x):
+        x = x.detach().float().clone().contiguous()
+        self.run(x)
+        return x
+
+
+# ================================================================================================
+# MSA update with pair
+# ================================================================================================
+class Symmetrization(nn.Module):
+    """rf.py:550-556 (container; the arithmetic is fused into rf_sym_layernorm)."""
+
+    def forward(self, x):
+        xt = torch.empty_like(x)
+        B, Lr, _, D = x.shape
+        ops.copy4d(x.contiguous(), (Lr * Lr * D, D, Lr * D, 1), xt, (Lr * Lr * D, Lr * D, D, 1), (B, Lr, Lr, D))
+        return ops.axpby(x.contiguous(), 0.5, xt, 0.5, torch.empty_like(x))
+
+
+class MsaUpdateWithPairLayer(RFModule):
+    """rf.py:559-595."""
+
+    def __init__(self, d_msa, d_pair, n_heads, p_dropout=0.1):
+        super().__init__()
+        self.n_heads = n_heads
+        self.pair2att = nn.Sequential(Symmetrization(), nn.LayerNorm(d_pair), nn.Linear(d_pair, n_heads),
+                                      nn.Dropout(p_dropout), nn.Identity(), nn.Softmax(dim=-1))
+        self.msa2value = nn.Sequential(nn.LayerNorm(d_msa), nn.Linear(d_msa, d_msa), nn.Identity())
+        self.ff = Residual(nn.Sequential(nn.LayerNorm(d_msa), FeedForward(d_msa, d_msa, p_dropout)), p_dropout=p_dropout)
+
+    def folded_att_proj(self):
+        """LayerNorm affine folded into the 288->H projection: W' = W*gamma, b' = W beta + b (fp32)."""
+        lnm, lin = self.pair2att[1], self.pair2att[2]
+        w = lin.weight.detach().float() * lnm.weight.detach().float()[None, :]
+        b = lin.weight.detach().float() @ lnm.bias.detach().float() + lin.bias.detach().float()
+        return w, b
+
+    def run(self, msa, att):
+        """msa fp32 [B,N,L,D] in place; att: T [H,B,L,L] (softmax over the last dim)."""
+        B, N, Lr, D = msa.shape
+        H = self.n_heads
+        dv = D // H
+        v_t = torch.empty(B, N, D, Lr, device=msa.device, dtype=T())
+        lin = self.msa2value[1]
+        ops.gemm(self.wt("v", lin), ln(self.msa2value[0], msa), v_t, D, Lr, D, batch=(B * N, 1, 1), b_bs=(Lr * D, 0, 0),
+                 c_bs=(D * Lr, 0, 0), c_row=(0, 0, Lr), bias=_f(lin.bias), bias_mode=L.BIAS_ROW)
+        # msa += att @ v  (rf.py:592-595), scattered back to [b,n,i,(h,d)]
+        ops.gemm(att, v_t, msa, Lr, N * dv, Lr, batch=(H, B, 1),
+                 a_bs=(B * Lr * Lr, Lr * Lr, 0), a_row=(0, 0, Lr),
+                 b_bs=(dv * Lr, N * D * Lr, 0), b_row=(dv, D * Lr, Lr),
+                 c_bs=(dv, N * Lr * D, 0), c_row=(0, 0, D), c_col=(dv, Lr * D), residual=msa)
+        self.ff.fn[1].apply_residual(ln(self.ff.fn[0], msa), msa)
+
+
+def pair_to_att(layers, pair):
+    """Shared front of the MsaUpdateWithPairLayer stack of one block (they all see the same pair):
+    one symmetrise+normalise pass, one GEMM for every layer's head logits, per-(layer,head) softmax.
+    Returns a list of T [H,B,L,L]."""
+    B, Lr, _, Dp = pair.shape
+    H = layers[0].n_heads
+    nl = len(layers)
+    xs = ops.sym_layernorm(pair, T(), eps=layers[0].pair2att[1].eps)
+    holder = layers[0]
+
+    def fold():
+        ws, bs = zip(*[l.folded_att_proj() for l in layers])
+        return torch.cat(ws, 0).to(T()).contiguous(), torch.cat(bs, 0).contiguous()
+
+    wc, bc = holder.cached(("att_fold", nl), fold)
+    logits = ops.linear(xs, wc, bc, out_dtype=F32)  # [B,L,L,nl*H]
+    NH = nl * H
+    atts = []
+    for li in range(nl):
+        att = torch.empty(H, B, Lr, Lr, device=pair.device, dtype=T())
+        for h in range(H):
+            ops.softmax(logits, li * H + h, Lr * NH, NH, att, h * B * Lr * Lr, Lr, B * Lr, Lr)
+        atts.append(att)
+    return atts
+
+
+class MsaUpdateWithPair(RFModule):
+    """rf.py:598-610 (the reference hides these layers in a plain list; here they are registered)."""
+
+    def __init__(self, d_msa, d_pair, n_heads, n_encoder_layers=4, p_dropout=0.1):
+        super().__init__()
+        self.encoder_layers = nn.ModuleList([MsaUpdateWithPairLayer(d_msa, d_pair, n_heads, p_dropout)
+                                             for _ in range(n_encoder_layers)])
+
+    def run(self, msa, pair):
+        atts = pair_to_att(list(self.encoder_layers), pair)
+        for layer, att in zip(self.encoder_layers, atts):
+            layer.run(msa, att)
+
+    def forward(self, msa, pair):
+        msa = msa.detach().float().clone().contiguous()
+        self.run(msa, pair.float().contiguous())
+        return msa
+
+
+def _msa_update_with_pair_layer_forward(self, msa, pair):
+    msa = msa.detach().float().clone().contiguous()
+    self.run(msa, pair_to_att([self], pair.float().contiguous())[0])
+    return msa
+
+
+MsaUpdateWithPairLayer.forward = _msa_update_with_pair_layer_forward
+
+
+# ================================================================================================
+# initial coordinates (graph transformer over the dense residue graph)
+# ================================================================================================
+class GraphTransformer(RFModule):
+    """rf.py:613-664."""
+
+    def __init__(self, d_node_in, d_node_out, d_edge, n_heads, p_dropout=0.15):
+        super().__init__()
+        self.scale = d_node_out ** (-0.5)
+        self.node_update = nn.Linear(d_node_in, d_node_out * n_heads, bias=True)
+        self.node_to_q = nn.Linear(d_node_in, d_node_out * n_heads, bias=True)
+        self.node_to_k = nn.Linear(d_node_in, d_node_out * n_heads, bias=True)
+        self.node_to_v = nn.Linear(d_node_in, d_node_out * n_heads, bias=True)
+        self.edge_emb = nn.Linear(d_edge, d_node_out * n_heads, bias=False)
+        self.n_heads, self.d_out = n_heads, d_node_out
+
+    def run(self, node, edge_t):
+        """node fp32 [B,L,dn]; edge_t T [B,L,L,de] -> fp32 [B,L,H*d]"""
+        B, Lr, _ = node.shape
+        H, d = self.n_heads, self.d_out
+        nt = ops.cast(node, T())
+        q = ops.linear(nt, self.wt("q", self.node_to_q), _f(self.node_to_q.bias))
+        k = ops.linear(nt, self.wt("k", self.node_to_k), _f(self.node_to_k.bias))
+        v = ops.linear(nt, self.wt("v", self.node_to_v), _f(self.node_to_v.bias))
+        e = ops.linear(edge_t, self.wt("e", self.edge_emb), None)
+        upd = torch.empty(B, Lr, H * d, device=node.device, dtype=F32)
+        ops.graph_attention(q, k, v, e, upd, B, Lr, H, d, self.scale)
+        return ops.linear(nt, self.wt("u", self.node_update), _f(self.node_update.bias), out_dtype=F32, residual=upd)
+
+    def forward(self, node_feat, edge_feat, edge_mask):
+        if edge_mask is not None:
+            raise NotImplementedError("edge_mask is unused on the forward path (rf.py:731)")
+        return self.run(node_feat.float().contiguous(), ops.cast(edge_feat.float().contiguous(), T()))
+
+
+class GraphTransformerBlock(RFModule):
+    """rf.py:667-676."""
+
+    def __init__(self, d_node_in, d_node_out, d_edge, n_heads, p_dropout=0.15):
+        super().__init__()
+        self.attn = GraphTransformer(d_node_in, d_node_out, d_edge, n_heads, p_dropout)
+        self.ln = nn.LayerNorm(d_node_out * n_heads)
+        self.to_out = nn.Sequential(nn.Linear(d_node_out * n_heads, d_node_in), nn.ELU())
+
+    def run(self, node, edge_t):
+        h = ln(self.ln, self.attn.run(node, edge_t))
+        return ops.linear(h, self.wt("o", self.to_out[0]), _f(self.to_out[0].bias), out_dtype=F32, act=L.ACT_ELU,
+                          residual=node)
+
+    def forward(self, node_feat, edge_feat, edge_mask):
+        return self.run(node_feat.float().contiguous(), ops.cast(edge_feat.float().contiguous(), T()))
+
+
+def _node_input(mod, msa, seq_onehot, out_dtype=None):
+    """[sum_n w*LN(msa) | onehot] zero-padded to a multiple of 8 columns, T (rf.py:715-724, 789-798)."""
+    B, N, Lr, D = msa.shape
+    m = ln(mod.ln_msa, msa)
+    w = mod.poswise_weight.weights_collapsed(msa, mod.ln_msa, m)
+    Kp = pad8(D + 21)
+    tmp = torch.zeros(B, Lr, Kp, device=msa.device, dtype=F32)
+    ops.weighted_msa_sum(m, w, tmp, Kp)
+    tmp[:, :, D:D + 21] = seq_onehot
+    return ops.cast(tmp, out_dtype or T()), Kp
+
+
+class InitialCoordGenerationWithMsaAndPair(RFModule):
+    """rf.py:679-749."""
+
+    def __init__(self, d_msa, d_pair, d_node=64, d_edge=64, n_heads=4, n_layers=4, p_dropout=0.1):
+        super().__init__()
+        self.ln_msa = nn.LayerNorm(d_msa)
+        self.ln_pair = nn.LayerNorm(d_pair)
+        self.poswise_weight = PositionWiseWeightFactor(d_msa, 1, p_dropout)
+        self.node_embed = nn.Sequential(nn.Linear(d_msa + 21, d_node), nn.ELU())
+        self.edge_embed = nn.Sequential(nn.Linear(d_pair + 1, d_edge), nn.ELU())
+        self.blocks = nn.ModuleList([GraphTransformerBlock(d_node, d_node, d_edge, n_heads, p_dropout)
+                                     for _ in range(n_layers)])
+        self.to_out = nn.Linear(d_node, 9)
+
+    def run(self, msa, pair, seq_onehot, aa_idx):
+        B, Lr, _, Dp = pair.shape
+        nin, Kp = _node_input(self, msa, seq_onehot)
+        node = ops.linear(nin, self.wt("n", self.node_embed[0], kpad=Kp), _f(self.node_embed[0].bias), out_dtype=F32,
+                          act=L.ACT_ELU)
+        Ke = pad8(Dp + 1)
+        ein = torch.zeros(B, Lr, Lr, Ke, device=pair.device, dtype=T())
+        ln(self.ln_pair, pair, out=ein, out_ld=Ke)
+        dist = aa_idx.unsqueeze(-1) - aa_idx.unsqueeze(-2)
+        ein[..., Dp] = (torch.sign(dist) * torch.log(torch.abs(dist) + 1)).clamp(0.0, 5.5).to(T())  # rf.py:746-749
+        edge = ops.linear(ein, self.wt("e", self.edge_embed[0], kpad=Ke), _f(self.edge_embed[0].bias), act=L.ACT_ELU)
+        for blk in self.blocks:
+            node = blk.run(node, edge)
+        xyz = ops.linear(ops.cast(node, T()), self.wt("o", self.to_out), _f(self.to_out.bias), out_dtype=F32)
+        return xyz.view(B, Lr, 3, 3)
+
+    def forward(self, msa, pair, seq_onehot, aa_idx):
+        return self.run(msa.float().contiguous(), pair.float().contiguous(), seq_onehot.float(), aa_idx)
+
+
+# ================================================================================================
+# prediction head (ResNet over the pair map)
+# ================================================================================================
+class ResBlock2D(RFModule):
+    """resnet.py:15-44."""
+
+    def __init__(self, channel, kernel_size, dilation, p_dropout=0.15):
+        super().__init__()
+        self.dilation = dilation
+        self.layer = Residual(nn.Sequential(
+            nn.Conv2d(channel, channel, kernel_size, dilation=dilation, padding="same", bias=False),
+            nn.InstanceNorm2d(channel, affine=True, eps=1e-6), nn.ELU(), nn.Dropout(p_dropout),
+            nn.Conv2d(channel, channel, kernel_size, dilation=dilation, padding="same", bias=False),
+            nn.InstanceNorm2d(channel, affine=True, eps=1e-6)))
+
+    def run(self, x_t, x_f):
+        """x_t: T NHWC (conv input), x_f: fp32 copy (residual).  Returns (T, fp32) of elu(block(x)+x)."""
+        f = self.layer.fn
+        y = conv3x3(self, "c1", f[0], x_t, self.dilation)
+        y, _ = ops.instnorm(y, _f(f[1].weight), _f(f[1].bias), eps=f[1].eps, act=L.ACT_ELU, out_dtype=T())
+        y = conv3x3(self, "c2", f[4], y, self.dilation)
+        o_f, o_t = ops.instnorm(y, _f(f[5].weight), _f(f[5].bias), eps=f[5].eps, residual=x_f, act=L.ACT_ELU,
+                                out_dtype=F32, out2_dtype=T())
+        return o_t, o_f
+
+    def forward(self, x):  # NCHW like the reference
+        xf = x.float().permute(0, 2, 3, 1).contiguous()
+        return self.run(ops.cast(xf, T()), xf)[1].permute(0, 3, 1, 2)
+
+
+class ResNet(RFModule):
+    """resnet.py:47-83."""
+
+    def __init__(self, n_res_blocks, in_channels, intermediate_channels, out_channels, dilations=[1, 2, 4, 8],
+                 p_dropout=0.15):
+        super().__init__()
+        layers = [nn.Conv2d(in_channels, intermediate_channels, 1, bias=False),
+                  nn.InstanceNorm2d(intermediate_channels, affine=True, eps=1e-6), nn.ELU()]
+        for b in range(n_res_blocks):
+            layers.append(ResBlock2D(intermediate_channels, kernel_size=3, dilation=dilations[b % len(dilations)],
+                                     p_dropout=p_dropout))
+        layers.append(nn.Conv2d(intermediate_channels, out_channels, 1))
+        self.layer = nn.Sequential(*layers)
+        self.n_res_blocks = n_res_blocks
+
+    def run(self, x_t):
+        """x_t: T NHWC -> fp32 NHWC logits."""
+        l0, l1 = self.layer[0], self.layer[1]
+        h = ops.linear(x_t, self.wt("in", l0), None)
+        h_f, h_t = ops.instnorm(h, _f(l1.weight), _f(l1.bias), eps=l1.eps, act=L.ACT_ELU, out_dtype=F32, out2_dtype=T())
+        for b in range(self.n_res_blocks):
+            h_t, h_f = self.layer[3 + b].run(h_t, h_f)
+        lo = self.layer[3 + self.n_res_blocks]
+        return ops.linear(h_t, self.wt("out", lo), _f(lo.bias), out_dtype=F32)
+
+    def forward(self, x):  # NCHW in / NCHW out like the reference
+        xf = x.float().permute(0, 2, 3, 1).contiguous()
+        return self.run(ops.cast(xf, T())).permute(0, 3, 1, 2)
+
+
+class PredictionHead(RFModule):
+    """rf.py:1130-1172."""
+
+    def __init__(self, in_channels, n_res_blocks, p_dropout):
+        super().__init__()
+        c = in_channels
+        self.proj = nn.Sequential(nn.LayerNorm(c), nn.Linear(c, c), nn.Dropout(p_dropout), nn.Identity())
+        self.dist_head = nn.Sequential(ResNet(n_res_blocks, c, c, 37, p_dropout=p_dropout), nn.Identity())
+        self.omega_head = nn.Sequential(ResNet(n_res_blocks, c, c, 37, p_dropout=p_dropout), nn.Identity())
+        self.theta_head = nn.Sequential(ResNet(n_res_blocks, c, c, 37, p_dropout=p_dropout), nn.Identity())
+        self.phi_head = nn.Sequential(ResNet(n_res_blocks, c, c, 19, p_dropout=p_dropout), nn.Identity())
+
+    def forward(self, pair):
+        pair = pair.float().contiguous()
+        B, Lr, _, Cc = pair.shape
+        x = ops.linear(ln(self.proj[0], pair), self.wt("p", self.proj[1]), _f(self.proj[1].bias), out_dtype=F32)
+        xt = torch.empty_like(x)
+        ops.copy4d(x, (Lr * Lr * Cc, Cc, Lr * Cc, 1), xt, (Lr * Lr * Cc, Lr * Cc, Cc, 1), (B, Lr, Lr, Cc))
+        xs = ops.axpby(x, 0.5, xt, 0.5, torch.empty(x.shape, device=x.device, dtype=T()))
+        x_t = ops.cast(x, T())
+        return {"theta": self.theta_head[0].run(x_t), "phi": self.phi_head[0].run(x_t),
+                "dist": self.dist_head[0].run(xs), "omega": self.omega_head[0].run(xs)}

@@ -135,10 +135,10 @@ def tied_softmax(logits, att, att_sym=None, sym_ld=0):
           "rf_tied_softmax")
 
 
-def poswise(q0, q0_ld, k, k_ld, k_col0, w, q_scale, qs_ld, qs_col0, B, N, L_, H, dh, scale, qscale):
+def poswise(q0, q0_ld, k, k_ld, k_col0, k_hs, dlen, w, q_scale, qs_ld, qs_col0, qs_dh, B, N, L_, H, scale, qscale):
     _need_cuda(q0, k, w, q_scale)
-    check(lib.rf_poswise(ptr(q0), q0_ld, ptr(k), k_ld, k_col0, ptr(w), ptr(q_scale), qs_ld, qs_col0, dcode(k.dtype),
-                         B, N, L_, H, dh, scale, qscale, stream()), "rf_poswise")
+    check(lib.rf_poswise(ptr(q0), dcode(q0.dtype), q0_ld, ptr(k), k_ld, k_col0, k_hs, dlen, ptr(w), ptr(q_scale),
+                         qs_ld, qs_col0, qs_dh, dcode(k.dtype), B, N, L_, H, scale, qscale, stream()), "rf_poswise")
 
 
 def weighted_msa_sum(x, w, y, y_ld):
@@ -311,3 +311,15 @@ def coord_apply(xyz, disp):
     out = torch.empty_like(xyz)
     check(lib.rf_coord_apply(ptr(xyz), ptr(disp), ptr(out), xyz.shape[0] * xyz.shape[1], stream()), "rf_coord_apply")
     return out
+
+
+def center_ca(xyz):
+    y = torch.empty_like(xyz)
+    check(lib.rf_center_ca(ptr(xyz), ptr(y), xyz.shape[0] * xyz.shape[1], stream()), "rf_center_ca")
+    return y
+
+
+def scale_rows(x, w, rows, D):
+    _need_cuda(x, w)
+    check(lib.rf_scale_rows(ptr(x), dcode(x.dtype), ptr(w), rows, D, stream()), "rf_scale_rows")
+    return x

@@ -1,0 +1,253 @@
+"""GPU parity: every module of the HIP path against the CPU oracle (oracle/rf_oracle.py) on the same seeded
+inputs and weights.  Two compute modes:
+  fp32 (exact fp32 GEMM tiles)  -> tolerance 2e-4 * max|ref|   (op order differs from ATen only)
+  bf16 (MFMA, fp32 accumulate)  -> tolerance 4e-2 * max|ref|   (operands rounded to 8 significant bits)
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+import rosettafold_pytorch_amd as R  # noqa: E402
+from oracle import rf_oracle as O  # noqa: E402
+
+DEV = "cuda"
+MODES = [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)]
+B, N, Lr, DM, DP, DN, DE, DS = 2, 8, 16, 96, 72, 8, 8, 8
+
+
+def rel(a, b):
+    """max |a-b| / max |b|"""
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-20)).item()
+
+
+def rel2(a, b):
+    """relative L2 error ||a-b|| / ||b||"""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rn(*s, seed=0):
+    return torch.randn(*s, generator=torch.Generator().manual_seed(seed + len(s) + sum(s)))
+
+
+def state(mod, prefix="m"):
+    return {prefix + "." + k: v.detach().float().cpu() for k, v in mod.state_dict().items()}
+
+
+def build(ctor, seed=11):
+    torch.manual_seed(seed)
+    return ctor().to(DEV)
+
+
+@pytest.fixture(params=MODES, ids=["fp32", "bf16"])
+def mode(request):
+    R.set_compute_dtype(request.param[0])
+    yield request.param
+    R.set_compute_dtype(torch.bfloat16)
+
+
+def xyz_trace(b, l, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    steps = torch.randn(b, l, 3, generator=g)
+    ca = torch.cumsum(3.8 * steps / steps.norm(dim=-1, keepdim=True), 1)
+    xyz = ca[:, :, None, :] + 0.5 * torch.randn(b, l, 3, 3, generator=g)
+    xyz[:, :, 1] = ca
+    return xyz
+
+
+AA = torch.stack([torch.arange(Lr), torch.arange(Lr) + torch.tensor([0] * 8 + [20] * 8)])
+
+
+def test_embeddings(mode):
+    g = torch.Generator().manual_seed(5)
+    msa = torch.randint(0, 21, (B, N, Lr), generator=g)
+    m = build(lambda: R.MsaEmbedding(21, DM, 64, 0.0))
+    assert rel(m(msa.to(DEV), AA.to(DEV)), O.msa_embedding(state(m), "m", msa, AA, 64)) < 1e-6
+    m = build(lambda: R.PairEmbedding(21, DP, 64, 0.0))
+    seq = msa[:, 0]
+    assert rel(m(seq.to(DEV), AA.to(DEV)), O.pair_embedding(state(m), "m", seq, AA, 64)) < 1e-5
+    with pytest.raises(ValueError):  # reference tests/test_module.py:134-143
+        m(seq.to(DEV), AA.to(DEV), template=torch.zeros(1))
+
+
+def test_poswise_weight(mode):
+    m = build(lambda: R.PositionWiseWeightFactor(DM, 12, 0.0))
+    x = rn(B, N, Lr, DM)
+    y = m(x.to(DEV))
+    assert rel(y, O.poswise_weight(state(m), "m", x, 12)) < mode[1]
+    assert rel(y.sum(1), torch.ones(B, 12, Lr, 1)) < 1e-5  # reference tests/test_module.py:180-200
+    with pytest.raises(AssertionError):  # reference tests/test_module.py:156-160
+        R.PositionWiseWeightFactor(100, 12)
+
+
+def test_soft_tied_attention(mode):
+    m = build(lambda: R.SoftTiedAttentionOverResidues(DM, 12, 0.0, return_att=True))
+    x = rn(B, N, Lr, DM)
+    out, att = m(x.to(DEV))
+    ro, ra = O.soft_tied_attention(state(m), "m", x, 12)
+    assert rel(out, ro) < mode[1] and rel(att, ra) < mode[1]
+    assert torch.equal(att, att.transpose(1, 2))
+
+
+def test_encoder_layers(mode):
+    m = build(lambda: R.EncoderLayer(d_msa=DM, d_ff=4 * DM, n_heads=12, p_dropout=0.0, tied=True, return_att=True))
+    x = rn(B, N, Lr, DM)
+    out, att = m(x.to(DEV))
+    ro, ra = O.encoder_layer_tied(state(m), "m", x, 12)
+    assert rel(out, ro) < mode[1] and rel(att, ra) < mode[1]
+    m = build(lambda: R.EncoderLayer(d_msa=DM, d_ff=4 * DM, n_heads=12, p_dropout=0.0, tied=False, performer=True))
+    assert rel(m(x.to(DEV)), O.encoder_layer_performer(state(m), "m", x, 12)) < mode[1]
+
+
+@pytest.mark.parametrize("generalized", [False, True])
+def test_performer_self_attention(mode, generalized):
+    m = build(lambda: R.PerformerSelfAttention(dim=DP, heads=8, generalized_attention=generalized))
+    x = rn(6, Lr, DP)
+    assert rel(m(x.to(DEV)), O.performer_self_attention(state(m), "m", x, 8, generalized)) < mode[1]
+
+
+def test_msa_update_using_self_attention(mode):
+    m = build(lambda: R.MsaUpdateUsingSelfAttention(d_msa=DM, d_ff=4 * DM, n_heads=12, p_dropout=0.0, n_encoder_layers=2))
+    x = rn(B, N, Lr, DM)
+    out, att = m(x.to(DEV))
+    ro, ra = O.msa_update_using_self_attention(state(m), "m", x, 2)
+    assert rel(out, ro) < mode[1] and rel(att, ra) < mode[1]
+
+
+def test_outer_product_and_pair_update_with_msa(mode):
+    m = build(lambda: R.OuterProductMean(32, DP))
+    xa, xb = rn(B, N, Lr, 32), rn(B, N, Lr, 32, seed=1)
+    assert rel(m(xa.to(DEV), xb.to(DEV)), O.outer_product_mean(state(m), "m", xa, xb)) < mode[1]
+    m = build(lambda: R.PairUpdateWithMsa(d_msa=DM, d_proj=32, d_pair=DP, n_heads=12, p_dropout=0.0))
+    msa, pair, att = rn(B, N, Lr, DM), rn(B, Lr, Lr, DP), torch.rand(B, Lr, Lr, 12)
+    assert rel(m(msa.to(DEV), pair.to(DEV), att.to(DEV)), O.pair_update_with_msa(state(m), "m", msa, pair, att)) < mode[1]
+
+
+def test_pair_axial_attention(mode):
+    m = build(lambda: R.PairUpdateWithAxialAttention(DP, 4 * DP, 8, 0.0, 2))
+    x = rn(B, Lr, Lr, DP)
+    assert rel(m(x.to(DEV)), O.pair_update_with_axial_attention(state(m), "m", x, 2)) < mode[1]
+
+
+def test_msa_update_with_pair(mode):
+    m = build(lambda: R.MsaUpdateWithPair(DM, DP, 4, n_encoder_layers=2, p_dropout=0.0))
+    msa, pair = rn(B, N, Lr, DM), rn(B, Lr, Lr, DP)
+    assert rel(m(msa.to(DEV), pair.to(DEV)), O.msa_update_with_pair(state(m), "m", msa, pair, 2, 4)) < mode[1]
+    sym = R.Symmetrization()(pair.to(DEV))
+    assert torch.equal(sym, sym.transpose(1, 2))  # reference tests/test_module.py:406-413
+
+
+def test_initial_coord_generation(mode):
+    m = build(lambda: R.InitialCoordGenerationWithMsaAndPair(DM, DP, d_node=DN, d_edge=DE, n_heads=4, n_layers=2, p_dropout=0.0))
+    msa, pair = rn(B, N, Lr, DM), rn(B, Lr, Lr, DP)
+    seq = torch.randint(0, 21, (B, Lr), generator=torch.Generator().manual_seed(1))
+    oh = torch.nn.functional.one_hot(seq, 21).float()
+    y = m(msa.to(DEV), pair.to(DEV), oh.to(DEV), AA.to(DEV))
+    assert rel(y, O.initial_coord_generation(state(m), "m", msa, pair, oh, AA, 2, 4)) < mode[1]
+
+
+@pytest.mark.parametrize("k", [4, 32])
+def test_knn_graph_bit_exact(k):
+    """edge lists are integer work: bit-exact against the oracle (itself pinned by the reference's golden lists)."""
+    from rosettafold_pytorch_amd import structure as S
+    xyz = xyz_trace(B, Lr)
+    edge = rn(B, Lr, Lr, DE)
+    g = S.build_graph(xyz.to(DEV), edge.to(DEV), AA.to(DEV), k)
+    n = int(g["count"].item())
+    b, i, j = O.knn_graph(xyz, AA, k)
+    assert n == b.numel() and n <= g["cap"]
+    assert torch.equal(g["src"][:n].cpu().long(), b * Lr + i) and torch.equal(g["dst"][:n].cpu().long(), b * Lr + j)
+    basis = O.se3_basis(xyz[b, j, 1] - xyz[b, i, 1])
+    got = g["basis"][:n].cpu()
+    assert rel(got[:, 0:1], basis[(0, 0)].reshape(n, 1)) < 1e-6
+    assert rel(got[:, 1:4], basis[(0, 1)].reshape(n, 3)) < 1e-5
+    assert rel(got[:, 4:7], basis[(1, 0)].reshape(n, 3)) < 1e-5
+    assert rel(got[:, 7:34], basis[(1, 1)].reshape(n, 27)) < 1e-5
+
+
+@pytest.mark.parametrize("k", [4, 32])
+def test_coord_update(mode, k):
+    m = build(lambda: R.CoordUpdateWithMsaAndPair(DM, DP, DN, DE, DS, n_neighbors=k, p_dropout=0.0))
+    msa, pair, xyz = rn(B, N, Lr, DM), rn(B, Lr, Lr, DP), xyz_trace(B, Lr)
+    seq = torch.randint(0, 21, (B, Lr), generator=torch.Generator().manual_seed(1))
+    oh = torch.nn.functional.one_hot(seq, 21).float()
+    st, xo = m(xyz.to(DEV), msa.to(DEV), pair.to(DEV), AA.to(DEV), oh.to(DEV))
+    rs, rx = O.coord_update(state(m), "m", xyz, msa, pair, AA, oh, k, DS)
+    if mode[0] == torch.float32:
+        assert rel(st, rs) < mode[1] and rel(xo, rx) < mode[1]
+    else:
+        # The reference network is discontinuous here: GNormBias on degree-0 features is relu(|v|+b)*sign(v)
+        # (ea/modules.py:391-406), so bf16-level input noise flips isolated outputs by O(1) -- the CPU oracle does
+        # the same under a 1e-3 input perturbation (DESIGN.md "Tolerances").  Robust bound: relative L2.
+        assert rel2(st, rs) < 0.3 and rel2(xo, rx) < 0.05
+
+
+def test_msa_update_with_pair_and_coord(mode):
+    m = build(lambda: R.MsaUpdateWithPairAndCoord(DM, DS, 32, 4 * DM, p_dropout=0.0))
+    msa, st, xyz = rn(B, N, Lr, DM), rn(B, Lr, DS), xyz_trace(B, Lr)
+    y = m(xyz.to(DEV), st.to(DEV), msa.to(DEV))
+    assert rel(y, O.msa_update_with_pair_and_coord(state(m), "m", xyz, st, msa)) < mode[1]
+
+
+def test_prediction_head(mode):
+    m = build(lambda: R.PredictionHead(DP, 4, 0.0))
+    pair = rn(B, Lr, Lr, DP)
+    out = m(pair.to(DEV))
+    ref = O.prediction_head(state(m), "m", pair, 4)
+    for k_ in ("theta", "phi", "dist", "omega"):
+        assert rel(out[k_], ref[k_]) < mode[1], k_
+    assert out["phi"].shape == (B, Lr, Lr, 19) and out["theta"].shape == (B, Lr, Lr, 37)
+
+
+CFG = dict(d_input=21, d_msa=DM, d_pair=DP, d_node=DN, d_edge=DE, d_state=DS, n_two_track_blocks=1,
+           n_three_track_blocks=2, n_encoder_layers=1, max_len=64, n_neighbors=[128, 128], p_dropout=0.0)
+
+
+def _run_full(cfg):
+    m = build(lambda: R.RoseTTAFold(**cfg))
+    g = torch.Generator().manual_seed(0)
+    msa = torch.randint(0, 21, (B, N, Lr), generator=g)
+    seq = msa[:, 0].clone()
+    logits, xyz, plddt = m(msa.to(DEV), seq.to(DEV), AA.to(DEV))
+    P = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    rl, rx, rp = O.rosettafold_forward(P, msa, seq, AA, cfg)
+    errs = {k_: (rel(logits[k_], rl[k_]), rel2(logits[k_], rl[k_])) for k_ in rl}
+    errs["xyz"] = (rel(xyz, rx), rel2(xyz, rx))
+    errs["plddt"] = (rel(plddt, rp), rel2(plddt, rp))
+    agree = (logits["dist"].argmax(-1).cpu() == rl["dist"].argmax(-1)).float().mean().item()
+    return logits, xyz, plddt, errs, agree
+
+
+def test_full_model_shapes_and_parity(mode):
+    """reference tests/test_module.py:792-824 (shape contract) + value parity with the oracle."""
+    logits, xyz, plddt, errs, agree = _run_full(CFG)
+    assert logits["theta"].shape == (B, Lr, Lr, 37) and logits["phi"].shape == (B, Lr, Lr, 19)
+    assert logits["dist"].shape == (B, Lr, Lr, 37) and logits["omega"].shape == (B, Lr, Lr, 37)
+    assert xyz.shape == (B, Lr, 3, 3) and plddt.shape == (B, Lr)
+    print(f"\n[{mode[0]}] full-model errors (max-rel, L2-rel): {errs}; distogram argmax agreement {agree:.4f}")
+    if mode[0] == torch.float32:
+        # exact-fp32 path: stated tolerance 5e-4 of the output range; distogram argmax bins bit-exact
+        assert all(e[0] < 5e-4 for e in errs.values()), errs
+        assert agree == 1.0
+    else:
+        # bf16 MFMA path with a three-track block in the stack: the structure module's discontinuities
+        # (test_coord_update) feed back into msa/pair, so only a robust bound holds at random init
+        assert all(e[1] < 0.3 for e in errs.values()), errs
+        assert agree > 0.75
+
+
+def test_full_model_smooth_path_bf16_tolerance(mode):
+    """n_three_track_blocks=1: the structure module only drives xyz/plddt, the logits see the smooth
+    (discontinuity-free) path -> this is where the bf16 tolerance of the MFMA path is stated: 6e-2 relative L2."""
+    cfg = dict(CFG, n_three_track_blocks=1)
+    logits, xyz, plddt, errs, agree = _run_full(cfg)
+    print(f"\n[{mode[0]}] smooth-path errors (max-rel, L2-rel): {errs}; distogram argmax agreement {agree:.4f}")
+    tol = 5e-4 if mode[0] == torch.float32 else 6e-2
+    for k_ in ("theta", "phi", "dist", "omega"):
+        assert errs[k_][1] < tol, (k_, errs[k_])
+    assert agree == 1.0 if mode[0] == torch.float32 else agree > 0.9
