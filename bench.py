@@ -172,11 +172,8 @@ def main():
     def step():
         logits, xyz, plddt = model(*inputs)
         if world > 1:  # the one collective of the path: gather the results on rank 0 (RCCL over xGMI)
-            import torch.distributed as dist
-            flat = torch.cat([logits[k].reshape(-1) for k in ("theta", "phi", "dist", "omega")]
-                             + [xyz.reshape(-1), plddt.reshape(-1)])
-            bufs = [torch.empty_like(flat) for _ in range(world)] if rank == 0 else None
-            dist.gather(flat, bufs, dst=0)
+            from rosettafold_pytorch_amd import shard
+            shard.gather_results(logits, xyz, plddt, dst=0)
         return logits
 
     def fence():
