@@ -1,0 +1,441 @@
+// Fused FAVOR+ (Performer) linear attention for gfx950: one persistent 4-wave workgroup per CU walks the
+// (batch, outer index, head) items; per item the whole chain
+//     k' = phi(k Pc^T)   ctx = k'^T v   ksum = sum_s k'      (phase A)
+//     q' = phi(q Pc^T)   out = (q' ctx) / (q' . ksum)        (phase B)
+// runs on-chip: q', k' and ctx never touch HBM (the unfused form moves ~5 GB per attention at config 2).
+// Replaces performer_pytorch.SelfAttention's fast_attention as called at rf.py:313-318 (softmax kernel,
+// MSA columns) and rf.py:505-518 (generalized ReLU kernel, pair rows/columns).  Third-party math restated
+// from the published algorithm (parity unpinned); checked against the oracle and against
+// the unfused kernel chain.
+//
+// MFMA plan (v_mfma_f32_16x16x32_bf16).  Accumulator tiles are consumed as operands of the next product
+// without leaving registers: a 16x16 f32 accumulator holds, per lane, 4 consecutive ROWS of one column, so
+// two vertically adjacent tiles give the 8 k-slots of an A/B fragment whose contraction index is the
+// accumulator's row index (k order permuted identically on the other operand):
+//   A1: D[s,m]   = K[s,:] . Pc[m,:]         A = K rows (LDS), B = Pc rows (registers, this wave's m slice)
+//   A2: ctx[m,d] += k'[s,m] v[s,d]          A = k' (from A1's accumulators), B = V via ds_read_b64_tr_b16
+//   B1: D[m,s]   = Pc[m,:] . Q[s,:]         A = Pc rows (LDS), B = Q rows (registers, this wave's s slice)
+//   B2: num[d,s] += ctx[m,d] q'[m,s]        A = ctx^T (LDS, bf16), B = q' (from B1's accumulators)
+// Phase A splits the 17 feature tiles (266 features) over the 4 waves, phase B splits the sequence.
+// K and V of the NEXT item are DMA-prefetched (global_load_lds) while phase B runs.
+#include "common.h"
+
+#define FV_DH 64
+#define FV_M 266
+#define FV_MT 17        // feature tiles of 16 that contain valid features
+#define FV_MPAD 288
+#define FV_CTX_LD 592   // bytes per ctx^T row (288 bf16 + pad: conflict-free ds_read_b64)
+
+struct FavorAttnP {
+  const bf16_t* qkv;  // [.., 3*inner] rows; q | k | v
+  const bf16_t* pc;   // [288][64] projection pre-scaled by d^-1/4, zero rows beyond 266
+  bf16_t* out;        // [.., inner]
+  int64_t x_b, x_o, x_s;  // element strides of qkv for batch / outer index / sequence index
+  int64_t o_b, o_o, o_s;  // same for out
+  int q_off, k_off, v_off;
+  int n_o, n_h, nitems;
+  float eps;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+__device__ __forceinline__ void fv_glds(const void* src, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// DMA a [nrows][64] bf16 tile (rows `stride` elements apart) into the swizzled LDS image at lds_off
+__device__ __forceinline__ void fv_load_tile(char* smem, int lds_off, const bf16_t* g, int64_t stride, int nrows,
+                                             int wave, int lane) {
+  const int ninstr = nrows * 8 / 64;
+  for (int it = wave; it < ninstr; it += 4) {
+    const int slot = it * 64 + lane;
+    const int row = slot >> 3;
+    const int clog = (slot & 7) ^ (row & 7);
+    fv_glds(g + (int64_t)row * stride + clog * 8, smem + lds_off + it * 1024);
+  }
+}
+
+__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }
+
+union Frag {
+  bf16x8 v;
+  unsigned u[4];
+  uint2 h[2];
+};
+
+template <int LS, bool SOFTMAX>
+__global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttnP p) {
+  constexpr int ST = LS / 64;    // s-tiles per wave in phase B
+  constexpr int NSB = LS / 32;   // s-blocks (pairs of s-tiles) in phase A
+  constexpr int PC_OFF = 0;
+  constexpr int K_OFF = FV_MPAD * 128;
+  constexpr int V_OFF = K_OFF + LS * 128;
+  constexpr int CTX_OFF = V_OFF + LS * 128;
+  constexpr int KSUM_OFF = CTX_OFF + FV_DH * FV_CTX_LD;
+  constexpr int DIAG_OFF = KSUM_OFF + FV_MPAD * 4;
+  constexpr int RED_OFF = DIAG_OFF + LS * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  // this wave's feature tiles in phase A: 5,4,4,4
+  const int nm = wave == 0 ? 5 : 4;
+  const int m0t = wave == 0 ? 0 : 5 + 4 * (wave - 1);
+
+  // one-time: projection image, zeroed ctx^T (its padded columns are read as MFMA operands)
+  fv_load_tile(smem, PC_OFF, p.pc, FV_DH, FV_MPAD, wave, lane);
+  for (int i = tid; i < FV_DH * FV_CTX_LD / 4; i += 256) ((unsigned*)(smem + CTX_OFF))[i] = 0u;
+  for (int i = tid; i < FV_MPAD; i += 256) ((float*)(smem + KSUM_OFF))[i] = 0.f;
+
+  auto item_base = [&](int item, int64_t& xb, int64_t& ob) {
+    const int h = item % p.n_h;
+    const int t = item / p.n_h;
+    const int o = t % p.n_o, b = t / p.n_o;
+    xb = (int64_t)b * p.x_b + (int64_t)o * p.x_o + h * FV_DH;
+    ob = (int64_t)b * p.o_b + (int64_t)o * p.o_o + h * FV_DH;
+  };
+
+  int item = blockIdx.x;
+  if (item < p.nitems) {
+    int64_t xb, ob;
+    item_base(item, xb, ob);
+    fv_load_tile(smem, K_OFF, p.qkv + xb + p.k_off, p.x_s, LS, wave, lane);
+    fv_load_tile(smem, V_OFF, p.qkv + xb + p.v_off, p.x_s, LS, wave, lane);
+  }
+  for (; item < p.nitems; item += gridDim.x) {
+    int64_t xb, ob;
+    item_base(item, xb, ob);
+    // Q fragments of this wave's rows straight from global (consumed in phase B)
+    bf16x8 qf[ST][2];
+#pragma unroll
+    for (int t = 0; t < ST; ++t) {
+      const int s = (wave * ST + t) * 16 + fr;
+      const bf16_t* qrow = p.qkv + xb + p.q_off + (int64_t)s * p.x_s;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) qf[t][kk] = *(const bf16x8*)(qrow + (kk * 4 + fq) * 8);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // K, V (and Pc on the first item) have landed; previous item fully consumed
+
+    float gmax = 0.f;
+    if constexpr (SOFTMAX) {
+      // diag_k[s] = |k_s|^2 / (2 sqrt(d)); one row per thread
+      for (int s = tid; s < LS; s += 256) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const bf16x8 x = *(const bf16x8*)(smem + K_OFF + s * 128 + c * 16);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = bf2f((bf16_t)x[e]);
+            a = fmaf(f, f, a);
+          }
+        }
+        ((float*)(smem + DIAG_OFF))[s] = a * 0.0625f;
+      }
+    }
+
+    // ---------------- phase A ----------------
+    bf16x8 pf[5][2];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        if (j < nm) pf[j][kk] = *(const bf16x8*)(smem + PC_OFF + swz_off((m0t + j) * 16 + fr, kk * 4 + fq));
+
+    if constexpr (SOFTMAX) {
+      // pass 0: global max of the key logits over (s, m < 266)
+      float mx = -INFINITY;
+      for (int u = 0; u < NSB; ++u) {
+        bf16x8 kf[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+            kf[t][kk] = *(const bf16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + fr, kk * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          if (j < nm) {
+            const bool valid = (m0t + j) * 16 + fr < FV_M;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              f32x4 a = {0.f, 0.f, 0.f, 0.f};
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], pf[j][0], a, 0, 0, 0);
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], pf[j][1], a, 0, 0, 0);
+              if (valid) mx = fmaxf(mx, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
+            }
+          }
+        }
+      }
+      mx = wave_max(mx);
+      if (lane == 0) ((float*)(smem + RED_OFF))[wave] = mx;
+      __syncthreads();  // also publishes diag_k
+      const float* red = (const float*)(smem + RED_OFF);
+      gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+
+    f32x4 ctx[5][4];
+    float ksum_p[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      ksum_p[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ctx[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int u = 0; u < NSB; ++u) {
+      bf16x8 kf[2][2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          kf[t][kk] = *(const bf16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + fr, kk * 4 + fq));
+      // V fragments (B operand, k = sequence): hardware-transposed reads of the row-major [s][d] image
+      Frag vf[4];
+      {
+        const int p4 = fr & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int row = u * 32 + half * 16 + 4 * fq + (fr >> 2);
+            const int off = V_OFF + swz_off(row, i * 2 + (p4 >> 1)) + (p4 & 1) * 8;
+            const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off));
+            vf[i].h[half] = __builtin_bit_cast(uint2, r);
+          }
+        }
+      }
+      float dg[2][4];
+      if constexpr (SOFTMAX) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float4 d4 = *(const float4*)(smem + DIAG_OFF + ((2 * u + t) * 16 + 4 * fq) * 4);
+          dg[t][0] = d4.x; dg[t][1] = d4.y; dg[t][2] = d4.z; dg[t][3] = d4.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        if (j < nm) {
+          f32x4 a[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            a[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            a[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], pf[j][0], a[t], 0, 0, 0);
+            a[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], pf[j][1], a[t], 0, 0, 0);
+          }
+          const bool valid = (m0t + j) * 16 + fr < FV_M;
+          float f[2][4];
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x;
+              if constexpr (SOFTMAX)
+                x = __expf(a[t][r] - dg[t][r] - gmax) + p.eps;
+              else
+                x = fmaxf(a[t][r], 0.f) + p.eps;
+              x = valid ? rbf(x) : 0.f;
+              f[t][r] = x;
+              ksum_p[j] += x;
+            }
+          Frag kfr;
+          kfr.u[0] = pack2(f[0][0], f[0][1]);
+          kfr.u[1] = pack2(f[0][2], f[0][3]);
+          kfr.u[2] = pack2(f[1][0], f[1][1]);
+          kfr.u[3] = pack2(f[1][2], f[1][3]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            ctx[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr.v, vf[i].v, ctx[j][i], 0, 0, 0);
+        }
+      }
+    }
+    // publish ctx^T (bf16) and ksum
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (j < nm) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          uint2 w;
+          w.x = pack2(ctx[j][i][0], ctx[j][i][1]);
+          w.y = pack2(ctx[j][i][2], ctx[j][i][3]);
+          *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ((m0t + j) * 16 + 4 * fq) * 2) = w;
+        }
+        float s = ksum_p[j];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (fq == 0) ((float*)(smem + KSUM_OFF))[(m0t + j) * 16 + fr] = s;
+      }
+    }
+    __syncthreads();  // ctx^T / ksum visible; K and V tiles are free again
+
+    // prefetch the next item's K and V while phase B runs
+    {
+      const int nxt = item + gridDim.x;
+      if (nxt < p.nitems) {
+        int64_t xb2, ob2;
+        item_base(nxt, xb2, ob2);
+        fv_load_tile(smem, K_OFF, p.qkv + xb2 + p.k_off, p.x_s, LS, wave, lane);
+        fv_load_tile(smem, V_OFF, p.qkv + xb2 + p.v_off, p.x_s, LS, wave, lane);
+      }
+    }
+
+    // ---------------- phase B ----------------
+    float dq[ST], rmax[ST];
+    if constexpr (SOFTMAX) {
+#pragma unroll
+      for (int t = 0; t < ST; ++t) {
+        float a = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = bf2f((bf16_t)qf[t][kk][e]);
+            a = fmaf(f, f, a);
+          }
+        a += __shfl_xor(a, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        dq[t] = a * 0.0625f;
+        rmax[t] = -INFINITY;
+      }
+      // pass 0: per-row max of the query logits over m < 266
+      for (int j = 0; j < FV_MT; ++j) {
+        bf16x8 pfr[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) pfr[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off(j * 16 + fr, kk * 4 + fq));
+#pragma unroll
+        for (int t = 0; t < ST; ++t) {
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[0], qf[t][0], a, 0, 0, 0);
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[1], qf[t][1], a, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (j * 16 + 4 * fq + r < FV_M) rmax[t] = fmaxf(rmax[t], a[r]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < ST; ++t) {
+        rmax[t] = fmaxf(rmax[t], __shfl_xor(rmax[t], 16, 64));
+        rmax[t] = fmaxf(rmax[t], __shfl_xor(rmax[t], 32, 64));
+      }
+    }
+    f32x4 num[4][ST];
+    float den[ST];
+#pragma unroll
+    for (int t = 0; t < ST; ++t) {
+      den[t] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) num[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (int u = 0; u < FV_MPAD / 32; ++u) {
+      float f[2][ST][4];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = 2 * u + jj;
+        if (j < FV_MT) {
+          bf16x8 pfr[2];
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) pfr[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off(j * 16 + fr, kk * 4 + fq));
+          const float4 ks = *(const float4*)(smem + KSUM_OFF + (j * 16 + 4 * fq) * 4);
+          const float ksv[4] = {ks.x, ks.y, ks.z, ks.w};
+#pragma unroll
+          for (int t = 0; t < ST; ++t) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[0], qf[t][0], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[1], qf[t][1], a, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x;
+              if constexpr (SOFTMAX)
+                x = __expf(a[r] - dq[t] - rmax[t]) + p.eps;
+              else
+                x = fmaxf(a[r], 0.f) + p.eps;
+              x = (j * 16 + 4 * fq + r < FV_M) ? rbf(x) : 0.f;
+              f[jj][t][r] = x;
+              den[t] = fmaf(x, ksv[r], den[t]);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < ST; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f[jj][t][r] = 0.f;
+        }
+      }
+      Frag cf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const char* base = smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + (32 * u + 4 * fq) * 2;
+        cf[i].h[0] = *(const uint2*)base;
+        cf[i].h[1] = *(const uint2*)(base + 32);
+      }
+#pragma unroll
+      for (int t = 0; t < ST; ++t) {
+        Frag qfr;
+        qfr.u[0] = pack2(f[0][t][0], f[0][t][1]);
+        qfr.u[1] = pack2(f[0][t][2], f[0][t][3]);
+        qfr.u[2] = pack2(f[1][t][0], f[1][t][1]);
+        qfr.u[3] = pack2(f[1][t][2], f[1][t][3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          num[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[i].v, qfr.v, num[i][t], 0, 0, 0);
+      }
+    }
+    // epilogue: out[s][h*64 + d] = num / den; lane owns 4 consecutive d of row s
+#pragma unroll
+    for (int t = 0; t < ST; ++t) {
+      float dn = den[t];
+      dn += __shfl_xor(dn, 16, 64);
+      dn += __shfl_xor(dn, 32, 64);
+      const float inv = 1.f / dn;
+      const int s = (wave * ST + t) * 16 + fr;
+      bf16_t* orow = p.out + ob + (int64_t)s * p.o_s;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint2 w;
+        w.x = pack2(num[i][t][0] * inv, num[i][t][1] * inv);
+        w.y = pack2(num[i][t][2] * inv, num[i][t][3] * inv);
+        *(uint2*)(orow + i * 16 + 4 * fq) = w;
+      }
+    }
+  }
+}
+
+template <int LS, bool SM>
+static int launch_favor(const FavorAttnP& p, hipStream_t s) {
+  const size_t lds = (size_t)FV_MPAD * 128 + 2 * (size_t)LS * 128 + (size_t)FV_DH * FV_CTX_LD + FV_MPAD * 4 + LS * 4 + 64;
+  auto k = favor_attention_kernel<LS, SM>;
+  static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  (void)once;
+  int ncu = 256;
+  const int grid = p.nitems < ncu ? p.nitems : ncu;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
+  return rf_launch_status();
+}
+
+extern "C" int rf_favor_attention(const void* qkv, const void* pc, void* out, const int64_t x_strides[3],
+                                  const int64_t o_strides[3], int q_off, int k_off, int v_off, int n_b, int n_o,
+                                  int n_h, int seq_len, int dim_head, int n_features, int softmax_kernel, float eps,
+                                  void* stream) {
+  if (dim_head != FV_DH || n_features != FV_M) return RF_EINVAL;
+  if (seq_len != 128 && seq_len != 256) return RF_EINVAL;
+  if (((uintptr_t)qkv % 16) || ((uintptr_t)pc % 16) || ((uintptr_t)out % 8)) return RF_EALIGN;
+  for (int i = 0; i < 3; ++i)
+    if (x_strides[i] % 8 || o_strides[i] % 4) return RF_EALIGN;
+  if (q_off % 8 || k_off % 8 || v_off % 8) return RF_EALIGN;
+  FavorAttnP p;
+  p.qkv = (const bf16_t*)qkv;
+  p.pc = (const bf16_t*)pc;
+  p.out = (bf16_t*)out;
+  p.x_b = x_strides[0]; p.x_o = x_strides[1]; p.x_s = x_strides[2];
+  p.o_b = o_strides[0]; p.o_o = o_strides[1]; p.o_s = o_strides[2];
+  p.q_off = q_off; p.k_off = k_off; p.v_off = v_off;
+  p.n_o = n_o; p.n_h = n_h;
+  p.nitems = n_b * n_o * n_h;
+  p.eps = eps;
+  hipStream_t s = (hipStream_t)stream;
+  if (seq_len == 256) return softmax_kernel ? launch_favor<256, true>(p, s) : launch_favor<256, false>(p, s);
+  return softmax_kernel ? launch_favor<128, true>(p, s) : launch_favor<128, false>(p, s);
+}

@@ -15,6 +15,8 @@
 //     (neighbouring N tiles of one activation row panel share an L2).
 //   * f32 path: exact fp32 FMA tiles (parity mode and the SE(3) module, which the reference
 //     forces to fp32: se3_modules.py:164).
+#include <type_traits>
+
 #include "common.h"
 
 __device__ __attribute__((aligned(16))) unsigned int g_rf_zero16[4];  // zero source for masked DMA lanes
@@ -23,6 +25,8 @@ struct GemmP {
   rf_gemm_desc d;
   int tilesM, tilesN;
   int vec_store;  // 1: 4-wide stores are legal for this C layout
+  int dbg;        // timing experiments: 1 = skip epilogue stores, 2 = skip the K loop
+  int stage_epi;  // 1: C tile goes through LDS and is written as whole rows (16-byte coalesced stores)
 };
 
 __device__ __forceinline__ int64_t split_off(int idx, int rc, int64_t ro, int64_t ri) {
@@ -62,6 +66,12 @@ __device__ __forceinline__ void store_scalar4(const rf_gemm_desc& d, int64_t c_r
 // ------------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
 // ------------------------------------------------------------------------------------------------
+// dynamic LDS per workgroup: the double-buffered operand tiles, or one fp32 row group of the staged epilogue
+__host__ __device__ constexpr int lds_bytes_for(int bm, int bn, int bk, int wgm) {
+  const int pipe = 2 * (bm + bn) * bk * 2, epi = wgm * 16 * (bn * 4 + 16);
+  return pipe > epi ? pipe : epi;
+}
+
 template <int BK>
 __device__ __forceinline__ int swz(int row) {
   if constexpr (BK == 64)
@@ -75,20 +85,22 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int BK, int AMODE>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
-  constexpr int SPR = BK / 8;  // 16-byte slots per tile row
+template <int BM, int BN, int BK, int WGM, int WGN, int AMODE>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const GemmP p) {
+  constexpr int NW = WGM * WGN;  // waves per workgroup, arranged WGM x WGN over the tile
+  constexpr int SPR = BK / 8;    // 16-byte slots per tile row
   constexpr int A_INSTR = BM * SPR / 64, B_INSTR = BN * SPR / 64;  // wave-level DMA instructions per tile
-  constexpr int A_PW = (A_INSTR + 3) / 4, B_PW = (B_INSTR + 3) / 4;
+  constexpr int A_PW = (A_INSTR + NW - 1) / NW, B_PW = (B_INSTR + NW - 1) / NW;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
-  constexpr int WM = BM / 32, WN = BN / 32;  // 16x16 MFMA tiles per wave (wave tile = BM/2 x BN/2)
+  constexpr int TM = BM / WGM, TN = BN / WGN;  // wave tile
+  constexpr int WM = TM / 16, WN = TN / 16;    // 16x16 MFMA tiles per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const rf_gemm_desc& d = p.d;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) % NW;
+  const int wm = wave / WGN, wn = wave % WGN;
 
   // XCD-aware bijective remap of the 1-D grid (round-robin dispatch puts block b on XCD b%8)
   int lid;
@@ -114,7 +126,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
   int a_ij[A_PW];  // conv: (i << 16) | j of the row's pixel
 #pragma unroll
   for (int t = 0; t < A_PW; ++t) {
-    const int slot = (t * 4 + wave) * 64 + lane;
+    const int slot = (t * NW + wave) * 64 + lane;
     int m = m0 + slot / SPR;
     m = m < d.M ? m : d.M - 1;
     if constexpr (AMODE == RF_AMODE_CONV3X3) {
@@ -129,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
   }
 #pragma unroll
   for (int t = 0; t < B_PW; ++t) {
-    const int slot = (t * 4 + wave) * 64 + lane;
+    const int slot = (t * NW + wave) * 64 + lane;
     int n = n0 + slot / SPR;
     n = n < d.N ? n : d.N - 1;
     b_src[t] = Bb + split_off(n, d.b_rc, d.b_ro, d.b_ri);
@@ -158,8 +170,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
     const bool kvalid = kpos < d.K;
 #pragma unroll
     for (int t = 0; t < A_PW; ++t) {
-      const int instr = t * 4 + wave;
-      if ((A_INSTR % 4 == 0) || instr < A_INSTR) {
+      const int instr = t * NW + wave;
+      if ((A_INSTR % NW == 0) || instr < A_INSTR) {
         bool ok = kvalid;
         if constexpr (AMODE == RF_AMODE_CONV3X3) {
           const int ii = (a_ij[t] >> 16) + cdi, jj = (a_ij[t] & 0xffff) + cdj;
@@ -171,8 +183,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
     }
 #pragma unroll
     for (int t = 0; t < B_PW; ++t) {
-      const int instr = t * 4 + wave;
-      if ((B_INSTR % 4 == 0) || instr < B_INSTR) {
+      const int instr = t * NW + wave;
+      if ((B_INSTR % NW == 0) || instr < B_INSTR) {
         const bf16_t* src = kvalid ? b_src[t] + b_koff : zsrc;
         glds16(src, b_lds + instr * 1024);
       }
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
   const int fr = lane & 15, fq = lane >> 4;
   const int nk = (d.K + BK - 1) / BK;
   stage(0);
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = 0; kt < ((p.dbg & 2) ? 1 : nk); ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile kt has landed for every wave; everyone is done reading the other buffer
     if (kt + 1 < nk) stage((kt + 1) & 1);
@@ -212,12 +224,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
       bf16x8 af[WM], bfr[WN];
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
-        const int row = wm * (BM / 2) + i * 16 + fr;
+        const int row = wm * TM + i * 16 + fr;
         af[i] = *(const bf16x8*)(a_lds + (row * SPR + ((kk * 4 + fq) ^ swz<BK>(row))) * 16);
       }
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
-        const int row = wn * (BN / 2) + j * 16 + fr;
+        const int row = wn * TN + j * 16 + fr;
         bfr[j] = *(const bf16x8*)(b_lds + (row * SPR + ((kk * 4 + fq) ^ swz<BK>(row))) * 16);
       }
 #pragma unroll
@@ -230,12 +242,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
   }
 
   // ---- epilogue: lane holds C[m][n..n+3], m = ..+fr, n = ..+4*fq --------------------------------
+  if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
   const int64_t c_z = z0 * d.c_bs[0] + z1 * d.c_bs[1] + z2 * d.c_bs[2];
   int64_t c_col[WN];
   float4 bias_c[WN];
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
-    const int n = n0 + wn * (BN / 2) + j * 16 + 4 * fq;
+    const int n = n0 + wn * TN + j * 16 + 4 * fq;
     c_col[j] = split_off(n, d.c_cc, d.c_co, 1);
     bias_c[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (d.bias_mode == RF_BIAS_COL) {
@@ -248,15 +261,90 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const GemmP p) {
       }
     }
   }
+  if (p.stage_epi) {
+    // Staged epilogue: the scattered 8-byte-per-lane stores of the MFMA layout are store-issue bound (they cost
+    // ~2/3 of a short-K GEMM); instead the C tile is written to LDS (the operand buffers are free now) and every
+    // thread then moves whole 16-byte chunks of consecutive rows -> full-line coalesced global stores.
+    auto staged = [&](auto esz_tag) {
+      constexpr int ESZ = decltype(esz_tag)::value;
+      constexpr int NT = 64 * NW;
+      constexpr int LDS_CAP = lds_bytes_for(BM, BN, BK, WGM);
+      constexpr int PITCH = BN * ESZ + 16;
+      constexpr int IPMAX = LDS_CAP / (WGM * 16 * PITCH);
+      static_assert(IPMAX >= 1, "C tile row group does not fit the operand buffers");
+      constexpr int IP = IPMAX < WM ? IPMAX : WM;
+      constexpr int CPR = BN * ESZ / 16;  // 16-byte chunks per tile row
+      constexpr int EPC = 16 / ESZ;       // elements per chunk
+#pragma unroll
+      for (int i0 = 0; i0 < WM; i0 += IP) {
+        __syncthreads();  // operand tiles (first pass) / previous pass fully consumed
+#pragma unroll
+        for (int ii = 0; ii < IP; ++ii) {
+          const int i = i0 + ii;
+          if (i < WM) {
+            const int m = m0 + wm * TM + i * 16 + fr;
+            const float bias_m = (d.bias_mode == RF_BIAS_ROW && m < d.M) ? d.bias[m] : 0.f;
+            char* lrow = smem + ((wm * IP + ii) * 16 + fr) * PITCH;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+              const int nl = wn * TN + j * 16 + 4 * fq;
+              const int n = n0 + nl;
+              float v[4];
+              const float bc[4] = {bias_c[j].x, bias_c[j].y, bias_c[j].z, bias_c[j].w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float x = acc[i][j][e] * d.alpha + bc[e] + bias_m;
+                v[e] = apply_act(x, d.act, d.act_eps, (d.act_nvalid < 0 ? m < -d.act_nvalid : n + e < d.act_nvalid));
+              }
+              if constexpr (ESZ == 4) {
+                *(float4*)(lrow + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+              } else {
+                uint2 o;
+                o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                *(uint2*)(lrow + nl * 2) = o;
+              }
+            }
+          }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < WGM * IP * 16 * CPR; idx += NT) {
+          const int lr = idx / CPR, c = idx % CPR;
+          const int w = lr / (IP * 16), rem = lr % (IP * 16);
+          const int i = i0 + rem / 16;
+          const int m = m0 + w * TM + i * 16 + (rem & 15);
+          const int n = n0 + c * EPC;
+          if (i >= WM || m >= d.M || n >= d.N) continue;
+          const int64_t c_off = c_z + split_off(m, d.c_rc, d.c_ro, d.c_ri) + split_off(n, d.c_cc, d.c_co, 1);
+          const char* src = smem + lr * PITCH + c * 16;
+          if constexpr (ESZ == 4) {
+            float4 v = *(const float4*)src;
+            if (d.residual) {
+              const float4 r = *(const float4*)(d.residual + c_off);
+              v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            *(float4*)((float*)d.C + c_off) = v;
+          } else {
+            *(uint4*)((bf16_t*)d.C + c_off) = *(const uint4*)src;
+          }
+        }
+      }
+    };
+    if (d.c_dtype == RF_F32)
+      staged(std::integral_constant<int, 4>{});
+    else
+      staged(std::integral_constant<int, 2>{});
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
-    const int m = m0 + wm * (BM / 2) + i * 16 + fr;
+    const int m = m0 + wm * TM + i * 16 + fr;
     if (m >= d.M) continue;
     const int64_t c_row = c_z + split_off(m, d.c_rc, d.c_ro, d.c_ri);
     const float bias_m = d.bias_mode == RF_BIAS_ROW ? d.bias[m] : 0.f;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 16 + 4 * fq;
+      const int n = n0 + wn * TN + j * 16 + 4 * fq;
       if (n >= d.N) continue;
       float v[4];
       const float bc[4] = {bias_c[j].x, bias_c[j].y, bias_c[j].z, bias_c[j].w};
@@ -372,7 +460,7 @@ struct TileCfg {
 };
 static const TileCfg kTiles[] = {
     {0, 0, 0},       // 0 = auto
-    {128, 128, 64},  // 1
+    {128, 128, 64},  // 1   (4 waves, 2x2)
     {128, 128, 32},  // 2
     {128, 96, 64},   // 3
     {128, 96, 32},   // 4
@@ -384,22 +472,28 @@ static const TileCfg kTiles[] = {
     {64, 96, 32},    // 10
     {64, 64, 64},    // 11
     {64, 64, 32},    // 12
+    {256, 256, 64},  // 13  (8 waves, 4x2: wave tile 64x128)
+    {256, 288, 64},  // 14  (8 waves, 4x2: wave tile 64x144)
+    {256, 192, 64},  // 15  (8 waves, 4x2: wave tile 64x96)
+    {256, 128, 64},  // 16  (8 waves, 4x2: wave tile 64x64)
+    {256, 256, 32},  // 17
+    {256, 288, 32},  // 18
 };
 static const int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int WGM, int WGN>
 static int launch_bf16(const GemmP& p, int64_t nblk, hipStream_t s) {
-  const size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
+  const size_t lds = lds_bytes_for(BM, BN, BK, WGM);
   if (p.d.a_mode == RF_AMODE_CONV3X3) {
-    auto k = gemm_bf16_kernel<BM, BN, BK, RF_AMODE_CONV3X3>;
+    auto k = gemm_bf16_kernel<BM, BN, BK, WGM, WGN, RF_AMODE_CONV3X3>;
     static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
     (void)once;
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(64 * WGM * WGN), lds, s, p);
   } else {
-    auto k = gemm_bf16_kernel<BM, BN, BK, RF_AMODE_PLAIN>;
+    auto k = gemm_bf16_kernel<BM, BN, BK, WGM, WGN, RF_AMODE_PLAIN>;
     static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
     (void)once;
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), lds, s, p);
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(64 * WGM * WGN), lds, s, p);
   }
   return rf_launch_status();
 }
@@ -421,6 +515,8 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   if (!dd || !dd->A || !dd->B || !dd->C) return RF_EINVAL;
   GemmP p;
   p.d = *dd;
+  p.dbg = (dd->tile_cfg >> 8) & 3;
+  p.d.tile_cfg &= 0xff;
   rf_gemm_desc& d = p.d;
   if (d.M <= 0 || d.N <= 0 || d.K <= 0) return RF_EINVAL;
   if (d.nb0 <= 0) d.nb0 = 1;
@@ -444,6 +540,15 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   const size_t esz = d.c_dtype == RF_F32 ? 4 : 2;
   if (((uintptr_t)d.C % (4 * esz)) != 0) p.vec_store = 0;
   if (d.residual && ((uintptr_t)d.residual % 16) != 0) p.vec_store = 0;
+  {
+    // staged (LDS -> coalesced 16-byte rows) epilogue legal?
+    const int epc = d.c_dtype == RF_F32 ? 4 : 8;
+    auto ok = [&](int64_t v) { return (v % epc) == 0; };
+    p.stage_epi = ok(d.N) && ok(d.c_ri) && (d.c_rc <= 0 || ok(d.c_ro)) && (d.c_cc <= 0 || (ok(d.c_cc) && ok(d.c_co))) &&
+                  ok(d.c_bs[0]) && ok(d.c_bs[1]) && ok(d.c_bs[2]) && ((uintptr_t)d.C % 16) == 0 &&
+                  (!d.residual || (d.c_dtype == RF_F32 && ((uintptr_t)d.residual % 16) == 0));
+    if (getenv("RF_NO_STAGED_EPILOGUE")) p.stage_epi = 0;
+  }
   hipStream_t s = (hipStream_t)stream;
 
   if (d.ab_dtype == RF_F32) {
@@ -472,29 +577,41 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   if (d.tile_cfg > 0 && d.tile_cfg < kNumTiles) {
     t = kTiles[d.tile_cfg];
   } else {
-    t.bn = pick_bn(d.N);
-    t.bm = d.M > 64 && ((d.M + 127) / 128) * 128 <= ((d.M + 63) / 64) * 64 + 32 ? 128 : 64;
-    t.bk = (d.K % 64 == 0 && d.kc % 64 == 0) ? 64 : 32;
-    if (d.K < 64) t.bk = 32;
+    t.bk = d.K >= 64 ? 64 : 32;  // BK=64 also for K % 64 != 0: the K tail is DMA'd from the zero word
+    const int64_t rows = (int64_t)d.M * batch;
+    if (d.M >= 1024 && rows >= 16384 && t.bk == 64 && (d.N % 288 == 0 || d.N % 256 == 0 || d.N % 192 == 0 || d.N == 128)) {
+      // long activation panels: 8-wave 256-row tiles halve the DMA bytes per FLOP
+      t.bm = 256;
+      t.bn = d.N % 288 == 0 ? 288 : (d.N % 256 == 0 ? 256 : (d.N % 192 == 0 ? 192 : 128));
+    } else {
+      t.bn = pick_bn(d.N);
+      t.bm = d.M > 64 && ((d.M + 127) / 128) * 128 <= ((d.M + 63) / 64) * 64 + 32 ? 128 : 64;
+    }
   }
   p.tilesM = (d.M + t.bm - 1) / t.bm;
   p.tilesN = (d.N + t.bn - 1) / t.bn;
   const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
   if (nblk > 0x7fffffffLL) return RF_EINVAL;
-#define RF_CASE(BM_, BN_, BK_) \
-  if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) return launch_bf16<BM_, BN_, BK_>(p, nblk, s);
-  RF_CASE(128, 128, 64)
-  RF_CASE(128, 128, 32)
-  RF_CASE(128, 96, 64)
-  RF_CASE(128, 96, 32)
-  RF_CASE(128, 64, 64)
-  RF_CASE(128, 64, 32)
-  RF_CASE(64, 128, 64)
-  RF_CASE(64, 128, 32)
-  RF_CASE(64, 96, 64)
-  RF_CASE(64, 96, 32)
-  RF_CASE(64, 64, 64)
-  RF_CASE(64, 64, 32)
+#define RF_CASE(BM_, BN_, BK_, WGM_, WGN_) \
+  if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) return launch_bf16<BM_, BN_, BK_, WGM_, WGN_>(p, nblk, s);
+  RF_CASE(128, 128, 64, 2, 2)
+  RF_CASE(128, 128, 32, 2, 2)
+  RF_CASE(128, 96, 64, 2, 2)
+  RF_CASE(128, 96, 32, 2, 2)
+  RF_CASE(128, 64, 64, 2, 2)
+  RF_CASE(128, 64, 32, 2, 2)
+  RF_CASE(64, 128, 64, 2, 2)
+  RF_CASE(64, 128, 32, 2, 2)
+  RF_CASE(64, 96, 64, 2, 2)
+  RF_CASE(64, 96, 32, 2, 2)
+  RF_CASE(64, 64, 64, 2, 2)
+  RF_CASE(64, 64, 32, 2, 2)
+  RF_CASE(256, 256, 64, 4, 2)
+  RF_CASE(256, 288, 64, 4, 2)
+  RF_CASE(256, 192, 64, 4, 2)
+  RF_CASE(256, 128, 64, 4, 2)
+  RF_CASE(256, 256, 32, 4, 2)
+  RF_CASE(256, 288, 32, 4, 2)
 #undef RF_CASE
   return RF_EINVAL;
 }

@@ -33,6 +33,7 @@ VT_ROWS = 80   # 64 value rows + the ones row (k' sums) padded to a multiple of 
 
 class _Runtime:
     dtype = torch.bfloat16
+    fused_favor = True  # use the fused FAVOR+ kernel when the shape allows (bf16, dim_head 64, seq 128/256)
 
 
 RT = _Runtime()
@@ -376,6 +377,15 @@ class PerformerSelfAttention(RFModule):
         m = self.fast_attention.projection_matrix.shape[0]
         pc = self.proj_scaled()
         gen = self.generalized
+        if RT.fused_favor and T() == torch.bfloat16 and dh == 64 and m == M_FEAT and Ls in (128, 256):
+            # fused path: one projection GEMM (q|k|v) + one persistent kernel; q', k', ctx never leave the chip
+            W3 = 3 * inner
+            qkv = ops.linear(xn, self.wcat("qkv", [self.to_q, self.to_k, self.to_v]), None)
+            o = torch.empty(R, inner, device=dev, dtype=T())
+            ops.favor_attention(qkv, pc, o, (RB * W3, so * W3, ss * W3), (RB * inner, so * inner, ss * inner),
+                                0, inner, 2 * inner, B, Lo, H, Ls, dh, m, not gen, 1e-3 if gen else 1e-4)
+            ops.linear(o, self.wt("o", self.to_out), _f(self.to_out.bias), out=x_res, residual=x_res)
+            return
         qk = ops.linear(xn, self.wcat("qk", [self.to_q, self.to_k]), None)  # [R, 2*inner]
         # q' [B,Lo,H,Ls,M_PAD]
         dq = torch.empty(B, Lo, H, Ls, M_PAD, device=dev, dtype=T())

@@ -323,3 +323,16 @@ def scale_rows(x, w, rows, D):
     _need_cuda(x, w)
     check(lib.rf_scale_rows(ptr(x), dcode(x.dtype), ptr(w), rows, D, stream()), "rf_scale_rows")
     return x
+
+
+def favor_attention(qkv, pc, out, x_strides, o_strides, q_off, k_off, v_off, n_b, n_o, n_h, seq_len, dim_head,
+                    n_features, softmax_kernel, eps):
+    _need_cuda(qkv, pc, out)
+    if qkv.dtype != BF16 or pc.dtype != BF16 or out.dtype != BF16:
+        raise TypeError("favor_attention is the bf16 MFMA path")
+    xs = L.I64x3(*[int(v) for v in x_strides])
+    os_ = L.I64x3(*[int(v) for v in o_strides])
+    check(lib.rf_favor_attention(ptr(qkv), ptr(pc), ptr(out), C.byref(xs), C.byref(os_), q_off, k_off, v_off, n_b, n_o,
+                                 n_h, seq_len, dim_head, n_features, 1 if softmax_kernel else 0, eps, stream()),
+          "rf_favor_attention")
+    return out

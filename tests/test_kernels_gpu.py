@@ -25,7 +25,8 @@ def randn(*s, dtype=torch.float32, seed=0):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 2e-2), (torch.float32, 2e-5)])
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 288, 288), (1024, 384, 384), (130, 37, 96), (64, 80, 128),
+@pytest.mark.parametrize("M,N,K", [(20000, 288, 288), (20000, 1152, 288), (17000, 384, 768), (16500, 256, 512),
+                                   (256, 128, 64), (300, 288, 288), (1024, 384, 384), (130, 37, 96), (64, 80, 128),
                                    (257, 1152, 288), (96, 288, 1152), (512, 96, 736)])
 def test_linear(dtype, tol, M, N, K):
     x, w, b = randn(M, K, dtype=dtype), randn(N, K, dtype=dtype, seed=1), randn(N, seed=2)
@@ -38,9 +39,9 @@ def test_linear(dtype, tol, M, N, K):
     assert rel_err(y, torch.relu(ref) + res) < tol
 
 
-@pytest.mark.parametrize("cfg", list(range(1, 13)))
+@pytest.mark.parametrize("cfg", list(range(1, 19)))
 def test_gemm_all_tile_configs(cfg):
-    M, N, K = 333, 200, 352
+    M, N, K = 777, 600, 352
     x, w = randn(M, K, dtype=torch.bfloat16), randn(N, K, dtype=torch.bfloat16, seed=1)
     y = ops.linear(x, w, None, out_dtype=torch.float32, tile_cfg=cfg)
     assert rel_err(y, x.float() @ w.float().t()) < 1e-2

@@ -111,6 +111,33 @@ def test_performer_self_attention(mode, generalized):
     assert rel(m(x.to(DEV)), O.performer_self_attention(state(m), "m", x, 8, generalized)) < mode[1]
 
 
+@pytest.mark.parametrize("generalized", [False, True])
+@pytest.mark.parametrize("n", [128, 256])
+def test_fused_favor_attention(generalized, n):
+    """fused FAVOR+ kernel (seq 128/256, bf16) vs the CPU oracle and vs the unfused kernel chain."""
+    R.set_compute_dtype(torch.bfloat16)
+    m = build(lambda: R.PerformerSelfAttention(dim=DP, heads=3, generalized_attention=generalized))
+    x = rn(5, n, DP)
+    ref = O.performer_self_attention(state(m), "m", x, 3, generalized)
+    R.RT.fused_favor = True
+    y_f = m(x.to(DEV))
+    R.RT.fused_favor = False
+    y_u = m(x.to(DEV))
+    R.RT.fused_favor = True
+    assert rel(y_u, ref) < 4e-2
+    assert rel(y_f, ref) < 4e-2, (rel(y_f, ref), rel(y_f, y_u))
+    assert rel2(y_f, ref) < 2e-2
+
+
+def test_fused_favor_axis1_strides():
+    """sequences along dim 1 (RowWise, rf.py:44-54): strided rows inside the fused kernel."""
+    R.set_compute_dtype(torch.bfloat16)
+    m = build(lambda: R.PairUpdateWithAxialAttentionLayer(DP, 4 * DP, 8, 0.0, {}))
+    x = rn(1, 128, 128, DP)
+    ref = O.pair_axial_layer(state(m), "m", x, 8)
+    assert rel(m(x.to(DEV)), ref) < 4e-2
+
+
 def test_msa_update_using_self_attention(mode):
     m = build(lambda: R.MsaUpdateUsingSelfAttention(d_msa=DM, d_ff=4 * DM, n_heads=12, p_dropout=0.0, n_encoder_layers=2))
     x = rn(B, N, Lr, DM)

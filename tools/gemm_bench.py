@@ -27,9 +27,14 @@ def main():
     shapes = [  # (M, N, K, tag)
         (262144, 1152, 288, "pair FF1"), (262144, 288, 1152, "pair FF2"), (262144, 1024, 288, "pair qk proj"),
         (131072, 1536, 384, "msa FF1"), (131072, 384, 1536, "msa FF2"), (131072, 1152, 384, "msa qkp proj"),
-        (262144, 288, 1024, "outer->pair"), (8192, 8192, 4096, "square-ish"), (4096, 4096, 4096, "4k cube"),
+        (262144, 288, 1024, "outer->pair"), (262144, 1536, 288, "pair qkv"), (262144, 288, 512, "pair attn out"),
+        (131072, 2304, 384, "msa qkv"), (131072, 384, 768, "msa attn out"), (262144, 288, 288, "pair proj"),
+        (8192, 8192, 4096, "square-ish"), (4096, 4096, 4096, "4k cube"),
     ]
-    cfgs = [int(c) for c in os.environ.get("CFGS", "0,1,2,3,4,5,7").split(",")]
+    cfgs = [int(c) for c in os.environ.get("CFGS", "0,1,3,13,14,15,16").split(",")]
+    only = os.environ.get("ONLY")
+    if only:
+        shapes = [s for s in shapes if s[3] in only.split(",")]
     for M, N, K, tag in shapes:
         x = torch.randn(M, K, device="cuda").bfloat16()
         w = torch.randn(N, K, device="cuda").bfloat16()
