@@ -68,6 +68,15 @@ def profile_gemms(model, inputs):
         torch.cuda.synchronize()
     finally:
         ops.lib.rf_gemm = orig
+    if os.environ.get("RF_GEMM_TABLE"):
+        tab = {}
+        for s, e, fl, dt, M, N, K, nb, amode in recs:
+            t = tab.setdefault((dt, amode, M, N, K, nb), [0.0, 0.0, 0])
+            t[0] += s.elapsed_time(e)
+            t[1] += fl
+            t[2] += 1
+        for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])[:40]:
+            log("gemm dt=%d conv=%d M=%d N=%d K=%d batch=%d : %d calls %.2f ms total, %.0f TF/s" % (*k, v[2], v[0], v[1] / v[0] / 1e9))
     fams = {}
     for s, e, fl, dt, M, N, K, nb, amode in recs:
         if dt != 1:
@@ -93,7 +102,9 @@ def cpu_baseline(cfg):
     from oracle import rf_oracle as O
     import rosettafold_pytorch_amd as R
     mc, N, L = cfg["model"], cfg["N"], cfg["L"]
-    ncores = os.cpu_count() or 1
+    # the GPU box grants a 16-CPU share per GPU: more threads than that only oversubscribe
+    ncores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1),
+                 int(os.environ.get("RF_CPU_THREADS", "16")))
     torch.set_num_threads(ncores)
     torch.manual_seed(1234)
     small = dict(mc, n_two_track_blocks=1, n_three_track_blocks=2, n_encoder_layers=1, p_dropout=0.0)

@@ -67,8 +67,8 @@ __device__ __forceinline__ void store_scalar4(const rf_gemm_desc& d, int64_t c_r
 // bf16 MFMA kernel
 // ------------------------------------------------------------------------------------------------
 // dynamic LDS per workgroup: the double-buffered operand tiles, or one fp32 row group of the staged epilogue
-__host__ __device__ constexpr int lds_bytes_for(int bm, int bn, int bk, int wgm) {
-  const int pipe = 2 * (bm + bn) * bk * 2, epi = wgm * 16 * (bn * 4 + 16);
+__host__ __device__ constexpr int lds_bytes_for(int bm, int bn, int bk, int wgm, int ns) {
+  const int pipe = ns * (bm + bn) * bk * 2 + (ns > 2 ? 1024 : 0), epi = wgm * 16 * (bn * 4 + 16);
   return pipe > epi ? pipe : epi;
 }
 
@@ -85,13 +85,16 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, int AMODE>
+template <int BM, int BN, int BK, int WGM, int WGN, int NS, int AMODE>
 __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const GemmP p) {
   constexpr int NW = WGM * WGN;  // waves per workgroup, arranged WGM x WGN over the tile
   constexpr int SPR = BK / 8;    // 16-byte slots per tile row
   constexpr int A_INSTR = BM * SPR / 64, B_INSTR = BN * SPR / 64;  // wave-level DMA instructions per tile
   constexpr int A_PW = (A_INSTR + NW - 1) / NW, B_PW = (B_INSTR + NW - 1) / NW;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int DUMP_OFF = NS * STAGE_BYTES;  // 1 KiB sink for the padding DMAs of the NS > 2 ring
+  constexpr int GLDS = A_PW + B_PW;           // DMA instructions per wave per stage (uniform when NS > 2)
   constexpr int TM = BM / WGM, TN = BN / WGN;  // wave tile
   constexpr int WM = TM / 16, WN = TN / 16;    // 16x16 MFMA tiles per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const GemmP p
   const bf16_t* const zsrc = (const bf16_t*)g_rf_zero16;
 
   auto stage = [&](int buf) {
-    char* a_lds = smem + buf * (A_BYTES + B_BYTES);
+    char* a_lds = smem + buf * STAGE_BYTES;
     char* b_lds = a_lds + A_BYTES;
     const bool kvalid = kpos < d.K;
 #pragma unroll
@@ -179,6 +182,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const GemmP p
         }
         const bf16_t* src = ok ? a_src[t] + a_koff : zsrc;
         glds16(src, a_lds + instr * 1024);
+      } else if constexpr (NS > 2) {
+        glds16(zsrc, smem + DUMP_OFF);  // keep the per-wave DMA count uniform for the counted vmcnt waits
       }
     }
 #pragma unroll
@@ -187,6 +192,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const GemmP p
       if ((B_INSTR % NW == 0) || instr < B_INSTR) {
         const bf16_t* src = kvalid ? b_src[t] + b_koff : zsrc;
         glds16(src, b_lds + instr * 1024);
+      } else if constexpr (NS > 2) {
+        glds16(zsrc, smem + DUMP_OFF);
       }
     }
     // advance this lane's K cursor by one step
@@ -212,12 +219,29 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const GemmP p
 
   const int fr = lane & 15, fq = lane >> 4;
   const int nk = (d.K + BK - 1) / BK;
-  stage(0);
-  for (int kt = 0; kt < ((p.dbg & 2) ? 1 : nk); ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // tile kt has landed for every wave; everyone is done reading the other buffer
-    if (kt + 1 < nk) stage((kt + 1) & 1);
-    const char* a_lds = smem + (kt & 1) * (A_BYTES + B_BYTES);
+  // DMA ring: NS stages, loads run NS-1 K steps ahead of the MFMAs.  A stage is consumed after (a) this wave's
+  // counted s_waitcnt vmcnt(GLDS * stages still allowed in flight) and (b) the workgroup barrier behind it; it is
+  // refilled one iteration after its last ds_read (every wave has passed the next barrier by then).
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < nk) stage(s0);
+  const int nk_run = (p.dbg & 2) ? 1 : nk;
+  for (int kt = 0; kt < nk_run; ++kt) {
+    if constexpr (NS == 2) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    } else {
+      const int younger = nk - 1 - kt < NS - 2 ? nk - 1 - kt : NS - 2;
+      if (younger >= 2)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GLDS) : "memory");
+      else if (younger == 1)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GLDS) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (kt + NS - 1 < nk) stage((kt + NS - 1) % NS);
+    const char* a_lds = smem + (kt % NS) * STAGE_BYTES;
     const char* b_lds = a_lds + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
@@ -268,7 +292,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const GemmP p
     auto staged = [&](auto esz_tag) {
       constexpr int ESZ = decltype(esz_tag)::value;
       constexpr int NT = 64 * NW;
-      constexpr int LDS_CAP = lds_bytes_for(BM, BN, BK, WGM);
+      constexpr int LDS_CAP = lds_bytes_for(BM, BN, BK, WGM, NS) - (NS > 2 ? 1024 : 0);
       constexpr int PITCH = BN * ESZ + 16;
       constexpr int IPMAX = LDS_CAP / (WGM * 16 * PITCH);
       static_assert(IPMAX >= 1, "C tile row group does not fit the operand buffers");
@@ -456,7 +480,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
 // host launcher
 // ------------------------------------------------------------------------------------------------
 struct TileCfg {
-  int bm, bn, bk;
+  int bm, bn, bk, ns = 2;
 };
 static const TileCfg kTiles[] = {
     {0, 0, 0},       // 0 = auto
@@ -478,19 +502,24 @@ static const TileCfg kTiles[] = {
     {256, 128, 64},  // 16  (8 waves, 4x2: wave tile 64x64)
     {256, 256, 32},  // 17
     {256, 288, 32},  // 18
+    {256, 256, 32, 4},  // 19  4-stage DMA ring (loads 3 K steps ahead)
+    {256, 288, 32, 4},  // 20
+    {256, 192, 32, 4},  // 21
+    {256, 128, 32, 4},  // 22
+    {128, 128, 32, 4},  // 23
 };
 static const int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-template <int BM, int BN, int BK, int WGM, int WGN>
+template <int BM, int BN, int BK, int WGM, int WGN, int NS>
 static int launch_bf16(const GemmP& p, int64_t nblk, hipStream_t s) {
-  const size_t lds = lds_bytes_for(BM, BN, BK, WGM);
+  const size_t lds = lds_bytes_for(BM, BN, BK, WGM, NS);
   if (p.d.a_mode == RF_AMODE_CONV3X3) {
-    auto k = gemm_bf16_kernel<BM, BN, BK, WGM, WGN, RF_AMODE_CONV3X3>;
+    auto k = gemm_bf16_kernel<BM, BN, BK, WGM, WGN, NS, RF_AMODE_CONV3X3>;
     static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
     (void)once;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(64 * WGM * WGN), lds, s, p);
   } else {
-    auto k = gemm_bf16_kernel<BM, BN, BK, WGM, WGN, RF_AMODE_PLAIN>;
+    auto k = gemm_bf16_kernel<BM, BN, BK, WGM, WGN, NS, RF_AMODE_PLAIN>;
     static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
     (void)once;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(64 * WGM * WGN), lds, s, p);
@@ -577,6 +606,7 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   if (d.tile_cfg > 0 && d.tile_cfg < kNumTiles) {
     t = kTiles[d.tile_cfg];
   } else {
+    t.ns = 2;
     t.bk = d.K >= 64 ? 64 : 32;  // BK=64 also for K % 64 != 0: the K tail is DMA'd from the zero word
     const int64_t rows = (int64_t)d.M * batch;
     if (d.M >= 1024 && rows >= 16384 && t.bk == 64 && (d.N % 288 == 0 || d.N % 256 == 0 || d.N % 192 == 0 || d.N == 128)) {
@@ -593,7 +623,9 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
   if (nblk > 0x7fffffffLL) return RF_EINVAL;
 #define RF_CASE(BM_, BN_, BK_, WGM_, WGN_) \
-  if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) return launch_bf16<BM_, BN_, BK_, WGM_, WGN_>(p, nblk, s);
+  if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_ && t.ns == 2) return launch_bf16<BM_, BN_, BK_, WGM_, WGN_, 2>(p, nblk, s);
+#define RF_CASE4(BM_, BN_, BK_, WGM_, WGN_) \
+  if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_ && t.ns == 4) return launch_bf16<BM_, BN_, BK_, WGM_, WGN_, 4>(p, nblk, s);
   RF_CASE(128, 128, 64, 2, 2)
   RF_CASE(128, 128, 32, 2, 2)
   RF_CASE(128, 96, 64, 2, 2)
@@ -612,6 +644,12 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   RF_CASE(256, 128, 64, 4, 2)
   RF_CASE(256, 256, 32, 4, 2)
   RF_CASE(256, 288, 32, 4, 2)
+  RF_CASE4(256, 256, 32, 4, 2)
+  RF_CASE4(256, 288, 32, 4, 2)
+  RF_CASE4(256, 192, 32, 4, 2)
+  RF_CASE4(256, 128, 32, 4, 2)
+  RF_CASE4(128, 128, 32, 2, 2)
+#undef RF_CASE4
 #undef RF_CASE
   return RF_EINVAL;
 }

@@ -79,10 +79,79 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* x, int x_dt,
   }
 }
 
+// Vectorised LayerNorm for the two residual streams (fp32 in, D % 4 == 0, D <= 1024): one wave per row,
+// 16-byte loads, NCH float4 chunks per lane, bf16 (8-byte) or fp32 (16-byte) stores; 2 rows in flight per wave.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int64_t x_ld, void* y, int y_dt, int64_t y_ld,
+                                                            int64_t rows, int D, const float* gamma, const float* beta,
+                                                            float eps, int act) {
+  const int lane = threadIdx.x & 63;
+  const int nch = D >> 2;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t row = wid; row < rows; row += nw) {
+    float4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+      const int c = lane + 64 * t;
+      v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < nch) v[t] = *(const float4*)(x + row * x_ld + 4 * c);
+      s += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+      const int c = lane + 64 * t;
+      if (c < nch) {
+        const float a = v[t].x - mean, b = v[t].y - mean, cc = v[t].z - mean, dd = v[t].w - mean;
+        q += (a * a + b * b) + (cc * cc + dd * dd);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+      const int c = lane + 64 * t;
+      if (c < nch) {
+        float o[4] = {(v[t].x - mean) * rstd, (v[t].y - mean) * rstd, (v[t].z - mean) * rstd, (v[t].w - mean) * rstd};
+        if (gamma) {
+          const float4 g = *(const float4*)(gamma + 4 * c), b = *(const float4*)(beta + 4 * c);
+          o[0] = o[0] * g.x + b.x; o[1] = o[1] * g.y + b.y; o[2] = o[2] * g.z + b.z; o[3] = o[3] * g.w + b.w;
+        }
+        if (act == RF_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        } else if (act == RF_ACT_LEAKY) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.01f * o[e];
+        }
+        if (y_dt == RF_F32) {
+          *(float4*)((float*)y + row * y_ld + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+          uint2 w;
+          w.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+          w.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+          *(uint2*)((bf16_t*)y + row * y_ld + 4 * c) = w;
+        }
+      }
+    }
+  }
+}
+
 template <bool SYM>
 static int launch_ln(const void* x, int x_dt, int64_t x_ld, void* y, int y_dt, int64_t y_ld, int64_t rows, int D,
                      const float* g, const float* b, float eps, int L, int groups, int act, hipStream_t s) {
   if (rows <= 0 || D <= 0 || D > 2304) return RF_EINVAL;
+  if (!SYM && x_dt == RF_F32 && groups <= 1 && D % 4 == 0 && D >= 128 && D <= 1024 && x_ld % 4 == 0 && y_ld % 4 == 0 &&
+      ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (!g || (((uintptr_t)g % 16) == 0 && ((uintptr_t)b % 16) == 0))) {
+    const unsigned gv = (unsigned)(rows < 8192 ? cdiv(rows, 4) : 2048);
+    if (D <= 512)
+      hipLaunchKernelGGL((layernorm_vec_kernel<2>), dim3(gv), dim3(256), 0, s, (const float*)x, x_ld, y, y_dt, y_ld, rows, D, g, b, eps, act);
+    else
+      hipLaunchKernelGGL((layernorm_vec_kernel<4>), dim3(gv), dim3(256), 0, s, (const float*)x, x_ld, y, y_dt, y_ld, rows, D, g, b, eps, act);
+    return rf_launch_status();
+  }
   const dim3 grid(cdiv(rows, 4)), blk(256);
 #define RF_LN(NV) hipLaunchKernelGGL((layernorm_kernel<NV, SYM>), grid, blk, 0, s, x, x_dt, x_ld, y, y_dt, y_ld, rows, D, g, b, eps, L, groups, act)
   if (D <= 64) RF_LN(1);
@@ -182,7 +251,28 @@ __global__ __launch_bounds__(256) void poswise_kernel(const void* q0, int q0_dt,
     const int64_t kb = (((int64_t)b * N + n) * L + l) * k_ld + k_col0 + h * k_hs;
     const int64_t qb = ((int64_t)b * L + l) * q0_ld + h * dlen;
     float a = 0.f;
-    for (int c = 0; c < dlen; ++c) a = fmaf(ld(q0, q0_dt, qb + c), ld(k, dt, kb + c), a);
+    if (dt == RF_BF16 && q0_dt == RF_BF16 && (dlen & 7) == 0 && ((kb | qb) & 7) == 0) {
+      const bf16x8* qp = (const bf16x8*)((const bf16_t*)q0 + qb);
+      const bf16x8* kp = (const bf16x8*)((const bf16_t*)k + kb);
+      for (int c = 0; c < (dlen >> 3); ++c) {
+        const bf16x8 qv = qp[c], kv = kp[c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a = fmaf(bf2f((bf16_t)qv[e]), bf2f((bf16_t)kv[e]), a);
+      }
+    } else if (dt == RF_BF16 && q0_dt == RF_F32 && (dlen & 7) == 0 && (kb & 7) == 0 && (qb & 3) == 0) {
+      const float4* qp = (const float4*)((const float*)q0 + qb);
+      const bf16x8* kp = (const bf16x8*)((const bf16_t*)k + kb);
+      for (int c = 0; c < (dlen >> 3); ++c) {
+        const bf16x8 kv = kp[c];
+        const float4 q1 = qp[2 * c], q2 = qp[2 * c + 1];
+        a = fmaf(q1.x, bf2f((bf16_t)kv[0]), a); a = fmaf(q1.y, bf2f((bf16_t)kv[1]), a);
+        a = fmaf(q1.z, bf2f((bf16_t)kv[2]), a); a = fmaf(q1.w, bf2f((bf16_t)kv[3]), a);
+        a = fmaf(q2.x, bf2f((bf16_t)kv[4]), a); a = fmaf(q2.y, bf2f((bf16_t)kv[5]), a);
+        a = fmaf(q2.z, bf2f((bf16_t)kv[6]), a); a = fmaf(q2.w, bf2f((bf16_t)kv[7]), a);
+      }
+    } else {
+      for (int c = 0; c < dlen; ++c) a = fmaf(ld(q0, q0_dt, qb + c), ld(k, dt, kb + c), a);
+    }
     sm[h * N + n] = a * scale;
   }
   __syncthreads();
@@ -204,7 +294,17 @@ __global__ __launch_bounds__(256) void poswise_kernel(const void* q0, int q0_dt,
     if (qs) {
       const int64_t o = (((int64_t)b * N + n) * L + l) * qs_ld + qs_col0 + h * qs_dh;
       const float f = wv_ * qscale;
-      for (int c = 0; c < qs_dh; ++c) st(qs, dt, o + c, ld(qs, dt, o + c) * f);
+      if (dt == RF_BF16 && (qs_dh & 7) == 0 && (o & 7) == 0) {
+        bf16x8* qp = (bf16x8*)((bf16_t*)qs + o);
+        for (int c = 0; c < (qs_dh >> 3); ++c) {
+          bf16x8 v = qp[c];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) * f);
+          qp[c] = v;
+        }
+      } else {
+        for (int c = 0; c < qs_dh; ++c) st(qs, dt, o + c, ld(qs, dt, o + c) * f);
+      }
     }
   }
 }

@@ -39,7 +39,7 @@ def test_linear(dtype, tol, M, N, K):
     assert rel_err(y, torch.relu(ref) + res) < tol
 
 
-@pytest.mark.parametrize("cfg", list(range(1, 19)))
+@pytest.mark.parametrize("cfg", list(range(1, 24)))
 def test_gemm_all_tile_configs(cfg):
     M, N, K = 777, 600, 352
     x, w = randn(M, K, dtype=torch.bfloat16), randn(N, K, dtype=torch.bfloat16, seed=1)
