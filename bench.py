@@ -59,7 +59,11 @@ def profile_gemms(model, inputs):
         e.record()
         d = desc._obj
         nb = max(d.nb0, 1) * max(d.nb1, 1) * max(d.nb2, 1)
-        recs.append((s, e, 2.0 * d.M * d.N * d.K * nb, d.ab_dtype, d.M, d.N, d.K, nb, d.a_mode))
+        esz = 2 if d.ab_dtype == 1 else 4
+        k_eff = d.K // 9 if d.a_mode == 1 else d.K  # conv: the image is read once algorithmically
+        nbytes = nb * (d.M * k_eff * esz + d.N * d.K * esz + d.M * d.N * (4 if d.c_dtype == 0 else 2)
+                       + (d.M * d.N * 4 if d.residual else 0))
+        recs.append((s, e, 2.0 * d.M * d.N * d.K * nb, d.ab_dtype, d.M, d.N, d.K, nb, d.a_mode, nbytes))
         return rc
 
     ops.lib.rf_gemm = wrapped
@@ -70,7 +74,7 @@ def profile_gemms(model, inputs):
         ops.lib.rf_gemm = orig
     if os.environ.get("RF_GEMM_TABLE"):
         tab = {}
-        for s, e, fl, dt, M, N, K, nb, amode in recs:
+        for s, e, fl, dt, M, N, K, nb, amode, _ in recs:
             t = tab.setdefault((dt, amode, M, N, K, nb), [0.0, 0.0, 0])
             t[0] += s.elapsed_time(e)
             t[1] += fl
@@ -78,17 +82,18 @@ def profile_gemms(model, inputs):
         for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])[:40]:
             log("gemm dt=%d conv=%d M=%d N=%d K=%d batch=%d : %d calls %.2f ms total, %.0f TF/s" % (*k, v[2], v[0], v[1] / v[0] / 1e9))
     fams = {}
-    for s, e, fl, dt, M, N, K, nb, amode in recs:
+    for s, e, fl, dt, M, N, K, nb, amode, nbytes in recs:
         if dt != 1:
             fam = "gemm_f32_kernel (fp32 tiles)"
         elif amode == 1:
             fam = "gemm_bf16_kernel<conv3x3> (MFMA 16x16x32)"
         else:
             fam = "gemm_bf16_kernel (MFMA 16x16x32)"
-        f = fams.setdefault(fam, [0.0, 0.0, 0])
+        f = fams.setdefault(fam, [0.0, 0.0, 0, 0.0])
         f[0] += s.elapsed_time(e) * 1e-3
         f[1] += fl
         f[2] += 1
+        f[3] += nbytes
     return fams, sum(r[0].elapsed_time(r[1]) for r in recs) * 1e-3
 
 
@@ -226,14 +231,25 @@ def main():
         }
         if world == 1 and not args.no_roofline:
             fams, tot = profile_gemms(model, inputs)
-            name, (secs, flops, n) = max(fams.items(), key=lambda kv: kv[1][0])
+            name, (secs, flops, n, nbytes) = max(fams.items(), key=lambda kv: kv[1][0])
+            traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic_pmc.json)
+            try:
+                with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as fh:
+                    pm = json.load(fh)["families"]
+                key = "gemm_bf16_kernel<conv3x3>" if "conv3x3" in name else "gemm_bf16_kernel"
+                traffic = pm[key]["hbm_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": flops / secs / 1e12,
                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": flops / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "frac": flops / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
                                "launches": n, "avg_launch_ms": 1e3 * secs / n,
                                "algorithmic_gflop_per_launch": flops / n / 1e9,
+                               "algorithmic_bytes_per_launch": nbytes / n,
+                               "algorithmic_hbm_GBps": nbytes / secs / 1e9, "hbm_peak_GBps": 8000.0,
                                "share_of_step": secs / (dt / args.steps),
-                               "families": {k: {"s": v[0], "tflops": v[1] / max(v[0], 1e-12) / 1e12, "n": v[2]}
+                               "families": {k: {"s": v[0], "tflops": v[1] / max(v[0], 1e-12) / 1e12, "n": v[2],
+                                                "algorithmic_GBps": v[3] / max(v[0], 1e-12) / 1e9}
                                             for k, v in fams.items()}}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)

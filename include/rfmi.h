@@ -76,6 +76,14 @@ typedef struct rf_gemm_desc {
   void* C;
   const float* bias;     /* fp32 */
   const float* residual; /* fp32, same layout as C; C = residual + epilogue(...) ; may alias C */
+  /* optional fused LayerNorm of the result rows (the next sub-layer's pre-norm, rf.py:341 etc.): when ln_out != NULL
+   * the kernel also writes ln_out[m, :] = LayerNorm(C[m, :]) * ln_gamma + ln_beta as bf16 [M, N] (row-major).
+   * Needs the bf16 path, plain fp32 C, one batch, N <= 384 (a workgroup then owns complete rows). */
+  void* ln_out;
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
+  int32_t reserved_;
 } rf_gemm_desc;
 
 int rf_gemm(const rf_gemm_desc* d, void* stream);

@@ -30,6 +30,7 @@ class GemmDesc(C.Structure):
         ("bias_mode", i32), ("act", i32), ("act_nvalid", i32),
         ("act_eps", f32), ("alpha", f32), ("tile_cfg", i32),
         ("A", vp), ("B", vp), ("C", vp), ("bias", vp), ("residual", vp),
+        ("ln_out", vp), ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32), ("reserved_", i32),
     ]
 
 

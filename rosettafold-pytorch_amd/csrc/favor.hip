@@ -109,7 +109,9 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
   for (; item < p.nitems; item += gridDim.x) {
     int64_t xb, ob;
     item_base(item, xb, ob);
-    // Q fragments of this wave's rows straight from global (consumed in phase B)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // K, V (and Pc on the first item) have landed; previous item fully consumed
+    // Q fragments of this wave's rows straight from global; consumed in phase B, so phase A hides the latency
     bf16x8 qf[ST][2];
 #pragma unroll
     for (int t = 0; t < ST; ++t) {
@@ -118,8 +120,6 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) qf[t][kk] = *(const bf16x8*)(qrow + (kk * 4 + fq) * 8);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // K, V (and Pc on the first item) have landed; previous item fully consumed
 
     float gmax = 0.f;
     if constexpr (SOFTMAX) {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
             a = fmaf(f, f, a);
           }
         }
-        ((float*)(smem + DIAG_OFF))[s] = a * 0.0625f;
+        ((float*)(smem + DIAG_OFF))[s] = a * (0.0625f * 1.4426950408889634f);  // log2 units (Pc carries log2 e)
       }
     }
 
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const float4 d4 = *(const float4*)(smem + DIAG_OFF + ((2 * u + t) * 16 + 4 * fq) * 4);
-          dg[t][0] = d4.x; dg[t][1] = d4.y; dg[t][2] = d4.z; dg[t][3] = d4.w;
+          dg[t][0] = d4.x + gmax; dg[t][1] = d4.y + gmax; dg[t][2] = d4.z + gmax; dg[t][3] = d4.w + gmax;
         }
       }
 #pragma unroll
@@ -226,7 +226,9 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
             a[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], pf[j][0], a[t], 0, 0, 0);
             a[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], pf[j][1], a[t], 0, 0, 0);
           }
-          const bool valid = (m0t + j) * 16 + fr < FV_M;
+          // only feature tile 16 (m = 256..271) holds padded features: mask there, nowhere else
+          const bool last_tile = (m0t + j) == FV_MT - 1;
+          const bool valid = !last_tile || fr < FV_M - 16 * (FV_MT - 1);
           float f[2][4];
 #pragma unroll
           for (int t = 0; t < 2; ++t)
@@ -234,13 +236,18 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
             for (int r = 0; r < 4; ++r) {
               float x;
               if constexpr (SOFTMAX)
-                x = __expf(a[t][r] - dg[t][r] - gmax) + p.eps;
+                x = __builtin_amdgcn_exp2f(a[t][r] - dg[t][r]) + p.eps;  // dg already holds diag + max (log2 units)
               else
-                x = fmaxf(a[t][r], 0.f) + p.eps;
-              x = valid ? rbf(x) : 0.f;
+                x = fmaxf(a[t][r] + p.eps, p.eps);
               f[t][r] = x;
-              ksum_p[j] += x;
             }
+          if (last_tile && !valid) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) f[t][r] = 0.f;
+          }
+          ksum_p[j] += ((f[0][0] + f[0][1]) + (f[0][2] + f[0][3])) + ((f[1][0] + f[1][1]) + (f[1][2] + f[1][3]));
           Frag kfr;
           kfr.u[0] = pack2(f[0][0], f[0][1]);
           kfr.u[1] = pack2(f[0][2], f[0][3]);
@@ -271,7 +278,9 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
     }
     __syncthreads();  // ctx^T / ksum visible; K and V tiles are free again
 
-    // prefetch the next item's K and V while phase B runs
+    // prefetch the next item's K and V while phase B runs.  The Q loads issued before phase A are drained first so
+    // the compiler's wait at their first use cannot turn into a wait for these DMAs.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
       const int nxt = item + gridDim.x;
       if (nxt < p.nitems) {
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
           }
         a += __shfl_xor(a, 16, 64);
         a += __shfl_xor(a, 32, 64);
-        dq[t] = a * 0.0625f;
+        dq[t] = a * (0.0625f * 1.4426950408889634f);
         rmax[t] = -INFINITY;
       }
       // pass 0: per-row max of the query logits over m < 266
@@ -345,14 +354,16 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[0], qf[t][0], a, 0, 0, 0);
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[1], qf[t][1], a, 0, 0, 0);
+            float off = 0.f;
+            if constexpr (SOFTMAX) off = dq[t] + rmax[t];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float x;
               if constexpr (SOFTMAX)
-                x = __expf(a[r] - dq[t] - rmax[t]) + p.eps;
+                x = __builtin_amdgcn_exp2f(a[r] - off) + p.eps;
               else
-                x = fmaxf(a[r], 0.f) + p.eps;
-              x = (j * 16 + 4 * fq + r < FV_M) ? rbf(x) : 0.f;
+                x = fmaxf(a[r] + p.eps, p.eps);
+              if (j == FV_MT - 1 && 4 * fq + r >= FV_M - 16 * (FV_MT - 1)) x = 0.f;
               f[jj][t][r] = x;
               den[t] = fmaf(x, ksv[r], den[t]);
             }

@@ -27,6 +27,7 @@ struct GemmP {
   int vec_store;  // 1: 4-wide stores are legal for this C layout
   int dbg;        // timing experiments: 1 = skip epilogue stores, 2 = skip the K loop
   int stage_epi;  // 1: C tile goes through LDS and is written as whole rows (16-byte coalesced stores)
+  int nt_store;   // 1: streaming (nontemporal) stores for large outputs
 };
 
 __device__ __forceinline__ int64_t split_off(int idx, int rc, int64_t ro, int64_t ri) {
@@ -332,24 +333,102 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const GemmP p
           }
         }
         __syncthreads();
-        for (int idx = tid; idx < WGM * IP * 16 * CPR; idx += NT) {
-          const int lr = idx / CPR, c = idx % CPR;
+        if constexpr (ESZ == 4) {
+          if (d.ln_out) {
+            // Fused "residual add + LayerNorm of the NEXT sub-layer": this tile spans complete rows (tilesN == 1), so
+            // one wave per staged row adds the residual, streams the fp32 row out, and emits the normalised row
+            // (the next GEMM's A operand) in the same pass -- the separate LayerNorm read of the stream disappears.
+            constexpr int ROWS_LN = WGM * IP * 16;
+            const int nch = d.N >> 2;
+            for (int lr = wave; lr < ROWS_LN; lr += NW) {
+              const int w = lr / (IP * 16), rem = lr % (IP * 16);
+              const int i = i0 + rem / 16;
+              const int m = m0 + w * TM + i * 16 + (rem & 15);
+              if (i >= WM || m >= d.M) continue;
+              const int64_t c_row = c_z + (int64_t)m * d.c_ri;
+              float4 v[2];
+              float sum = 0.f;
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                const int c = lane + 64 * t;
+                v[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < nch) {
+                  v[t] = *(const float4*)(smem + lr * PITCH + c * 16);
+                  if (d.residual) {
+                    const float4 r = *(const float4*)(d.residual + c_row + 4 * c);
+                    v[t].x += r.x; v[t].y += r.y; v[t].z += r.z; v[t].w += r.w;
+                  }
+                  if (p.nt_store)
+                    __builtin_nontemporal_store(*(f32x4*)&v[t], (f32x4*)((float*)d.C + c_row + 4 * c));
+                  else
+                    *(float4*)((float*)d.C + c_row + 4 * c) = v[t];
+                  sum += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+                }
+              }
+              const float mean = wave_sum(sum) / d.N;
+              float q = 0.f;
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                const int c = lane + 64 * t;
+                if (c < nch) {
+                  const float a = v[t].x - mean, b = v[t].y - mean, cc = v[t].z - mean, dd = v[t].w - mean;
+                  q += (a * a + b * b) + (cc * cc + dd * dd);
+                }
+              }
+              const float rstd = rsqrtf(wave_sum(q) / d.N + d.ln_eps);
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                const int c = lane + 64 * t;
+                if (c < nch) {
+                  const float4 g = *(const float4*)(d.ln_gamma + 4 * c), be = *(const float4*)(d.ln_beta + 4 * c);
+                  const float o0 = (v[t].x - mean) * rstd * g.x + be.x, o1 = (v[t].y - mean) * rstd * g.y + be.y;
+                  const float o2 = (v[t].z - mean) * rstd * g.z + be.z, o3 = (v[t].w - mean) * rstd * g.w + be.w;
+                  uint2 wv;
+                  wv.x = (unsigned)f2bf(o0) | ((unsigned)f2bf(o1) << 16);
+                  wv.y = (unsigned)f2bf(o2) | ((unsigned)f2bf(o3) << 16);
+                  *(uint2*)((bf16_t*)d.ln_out + (int64_t)m * d.N + 4 * c) = wv;
+                }
+              }
+            }
+            continue;
+          }
+        }
+        // each thread walks 16-byte chunks idx = tid, tid+NT, ... of the staged rows; (row, chunk) advance
+        // incrementally (no divisions in the loop).  Large outputs are streamed with nontemporal stores.
+        constexpr int ROWS = WGM * IP * 16;
+        constexpr int DR = NT / CPR, DC = NT % CPR;
+        const bool plain_c = d.c_rc <= 0 && d.c_cc <= 0;
+        int lr = tid / CPR, c = tid % CPR;
+        for (; lr < ROWS; lr += DR) {
           const int w = lr / (IP * 16), rem = lr % (IP * 16);
           const int i = i0 + rem / 16;
           const int m = m0 + w * TM + i * 16 + (rem & 15);
           const int n = n0 + c * EPC;
-          if (i >= WM || m >= d.M || n >= d.N) continue;
-          const int64_t c_off = c_z + split_off(m, d.c_rc, d.c_ro, d.c_ri) + split_off(n, d.c_cc, d.c_co, 1);
-          const char* src = smem + lr * PITCH + c * 16;
-          if constexpr (ESZ == 4) {
-            float4 v = *(const float4*)src;
-            if (d.residual) {
-              const float4 r = *(const float4*)(d.residual + c_off);
-              v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+          if (i < WM && m < d.M && n < d.N) {
+            const int64_t c_off = plain_c ? c_z + (int64_t)m * d.c_ri + n
+                                          : c_z + split_off(m, d.c_rc, d.c_ro, d.c_ri) + split_off(n, d.c_cc, d.c_co, 1);
+            const char* src = smem + lr * PITCH + c * 16;
+            if constexpr (ESZ == 4) {
+              float4 v = *(const float4*)src;
+              if (d.residual) {
+                const float4 r = *(const float4*)(d.residual + c_off);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+              }
+              if (p.nt_store)
+                __builtin_nontemporal_store(*(f32x4*)&v, (f32x4*)((float*)d.C + c_off));
+              else
+                *(float4*)((float*)d.C + c_off) = v;
+            } else {
+              if (p.nt_store)
+                __builtin_nontemporal_store(*(const f32x4*)src, (f32x4*)((bf16_t*)d.C + c_off));
+              else
+                *(uint4*)((bf16_t*)d.C + c_off) = *(const uint4*)src;
             }
-            *(float4*)((float*)d.C + c_off) = v;
-          } else {
-            *(uint4*)((bf16_t*)d.C + c_off) = *(const uint4*)src;
+          }
+          c += DC;
+          if (c >= CPR) {
+            c -= CPR;
+            ++lr;
           }
         }
       }
@@ -507,6 +586,7 @@ static const TileCfg kTiles[] = {
     {256, 192, 32, 4},  // 21
     {256, 128, 32, 4},  // 22
     {128, 128, 32, 4},  // 23
+    {128, 384, 64},     // 24  (8 waves, 4x2: wave tile 32x192) full 384-wide rows for the fused LayerNorm epilogue
 };
 static const int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -579,8 +659,10 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
     if (getenv("RF_NO_STAGED_EPILOGUE")) p.stage_epi = 0;
   }
   hipStream_t s = (hipStream_t)stream;
+  const bool want_ln = d.ln_out != nullptr;
 
   if (d.ab_dtype == RF_F32) {
+    if (want_ln) return RF_EINVAL;  // the fused LayerNorm epilogue exists on the bf16 MFMA path only
     p.tilesM = (d.M + 63) / 64;
     p.tilesN = (d.N + 63) / 64;
     const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
@@ -618,10 +700,20 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
       t.bm = d.M > 64 && ((d.M + 127) / 128) * 128 <= ((d.M + 63) / 64) * 64 + 32 ? 128 : 64;
     }
   }
+  if (want_ln) {
+    // needs complete rows per workgroup, plain fp32 C, <= 128 float4 chunks per row
+    if (!p.stage_epi || d.c_dtype != RF_F32 || d.c_rc > 0 || d.c_cc > 0 || batch != 1 || d.N > 512 || d.N % 4 ||
+        !d.ln_gamma || !d.ln_beta || ((uintptr_t)d.ln_out % 8) || ((uintptr_t)d.ln_gamma % 16) || ((uintptr_t)d.ln_beta % 16))
+      return RF_EINVAL;
+    if (d.N <= 288) { t.bm = 256; t.bn = 288; t.bk = 64; t.ns = 2; }
+    else if (d.N <= 384) { t.bm = 128; t.bn = 384; t.bk = 64; t.ns = 2; }
+    else return RF_EINVAL;
+  }
   p.tilesM = (d.M + t.bm - 1) / t.bm;
   p.tilesN = (d.N + t.bn - 1) / t.bn;
   const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
   if (nblk > 0x7fffffffLL) return RF_EINVAL;
+  p.nt_store = ((int64_t)d.M * d.N * batch * (d.c_dtype == RF_F32 ? 4 : 2) > (64ll << 20)) && !getenv("RF_NO_NT_STORE");
 #define RF_CASE(BM_, BN_, BK_, WGM_, WGN_) \
   if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_ && t.ns == 2) return launch_bf16<BM_, BN_, BK_, WGM_, WGN_, 2>(p, nblk, s);
 #define RF_CASE4(BM_, BN_, BK_, WGM_, WGN_) \
@@ -644,6 +736,7 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   RF_CASE(256, 128, 64, 4, 2)
   RF_CASE(256, 256, 32, 4, 2)
   RF_CASE(256, 288, 32, 4, 2)
+  RF_CASE(128, 384, 64, 4, 2)
   RF_CASE4(256, 256, 32, 4, 2)
   RF_CASE4(256, 288, 32, 4, 2)
   RF_CASE4(256, 192, 32, 4, 2)

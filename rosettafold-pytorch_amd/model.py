@@ -120,16 +120,17 @@ class FeedForward(RFModule):
         super().__init__()
         self.net = nn.Sequential(nn.Linear(d_emb, d_ff), nn.ReLU(), nn.Dropout(p_dropout), nn.Linear(d_ff, d_emb))
 
-    def apply_residual(self, xn, x_res):
-        """x_res += W2 relu(W1 xn + b1) + b2   (x_res fp32, in place)."""
+    def apply_residual(self, xn, x_res, next_ln=None):
+        """x_res += W2 relu(W1 xn + b1) + b2   (x_res fp32, in place).  With `next_ln` the second GEMM's epilogue also
+        emits next_ln(x_res) (returned, or None when the fused form does not apply)."""
         h = ops.linear(xn, self.wt("w1", self.net[0]), _f(self.net[0].bias), act=L.ACT_RELU)
-        ops.linear(h, self.wt("w2", self.net[3]), _f(self.net[3].bias), out=x_res, residual=x_res)
-        return x_res
+        return ops.linear_residual_ln(h, self.wt("w2", self.net[3]), _f(self.net[3].bias), x_res, next_ln)
 
     def forward(self, x):
         xn = ops.cast(x.contiguous(), T())
         out = torch.zeros(x.shape, device=x.device, dtype=F32)
-        return self.apply_residual(xn, out)
+        self.apply_residual(xn, out)
+        return out
 
 
 def sinusoid_table(dim, max_len):
@@ -271,9 +272,9 @@ class SoftTiedAttentionOverResidues(RFModule):
         self.to_v = nn.Linear(d_msa, d_msa)
         self.to_out = nn.Linear(d_msa, d_msa)
 
-    def attend(self, xn, x_res, want_att):
-        """xn: T [B,N,L,D] (already layer-normed); x_res: fp32 [B,N,L,D] += to_out(attention).  Returns the
-        symmetrised attention map fp32 [B,L,L,H] when want_att."""
+    def attend(self, xn, x_res, want_att, next_ln=None):
+        """xn: T [B,N,L,D] (already layer-normed); x_res: fp32 [B,N,L,D] += to_out(attention).  Returns
+        (symmetrised attention map fp32 [B,L,L,H] when want_att, next_ln(x_res) when fused else None)."""
         B, N, Lr, D = xn.shape
         H, dh = self.n_heads, self.d_head
         dev = xn.device
@@ -305,13 +306,13 @@ class SoftTiedAttentionOverResidues(RFModule):
                  a_bs=(H * Lr * Lr, Lr * Lr, 0), a_row=(0, 0, Lr),
                  b_bs=(N * D * Lr, dh * Lr, 0), b_row=(dh, D * Lr, Lr),
                  c_bs=(N * Lr * D, dh, 0), c_row=(0, 0, D), c_col=(dh, Lr * D))
-        ops.linear(out, self.wt("o", self.to_out), _f(self.to_out.bias), out=x_res, residual=x_res)
-        return att_sym
+        xn_next = ops.linear_residual_ln(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln)
+        return att_sym, xn_next
 
     def forward(self, x):
         xn = ops.cast(x.contiguous(), T())
         out = torch.zeros(x.shape, device=x.device, dtype=F32)
-        att = self.attend(xn, out, self.return_att)
+        att, _ = self.attend(xn, out, self.return_att)
         return (out, att) if self.return_att else out
 
 
@@ -354,17 +355,20 @@ class PerformerSelfAttention(RFModule):
         self.to_v = nn.Linear(dim, inner, bias=False)
         self.to_out = nn.Linear(inner, dim)
 
-    def proj_scaled(self):
+    def proj_scaled(self, log2e=False):
         def make():
             p = self.fast_attention.projection_matrix.detach().float() * self.dim_head ** -0.25
+            if log2e:  # the fused softmax-kernel variant exponentiates with exp2
+                p = p * 1.4426950408889634
             pp = p.new_zeros(M_PAD, self.dim_head)
             pp[: p.shape[0]] = p
             return pp.to(T()).contiguous()
-        return self.cached("proj", make)
+        return self.cached(("proj", log2e), make)
 
-    def attend(self, xn, x_res, axis):
+    def attend(self, xn, x_res, axis, next_ln=None):
         """xn: T [B,L1,L2,D] layer-normed input; sequences run along `axis` (1 or 2); x_res (fp32, same shape)
-        += to_out(linear attention).  All intermediates are addressed by strides: no transposes."""
+        += to_out(linear attention).  All intermediates are addressed by strides: no transposes.
+        Returns next_ln(x_res) when the fused residual+LayerNorm epilogue applies, else None."""
         B, L1, L2, D = xn.shape
         H, dh, inner = self.heads, self.dim_head, self.inner
         dev = xn.device
@@ -382,10 +386,10 @@ class PerformerSelfAttention(RFModule):
             W3 = 3 * inner
             qkv = ops.linear(xn, self.wcat("qkv", [self.to_q, self.to_k, self.to_v]), None)
             o = torch.empty(R, inner, device=dev, dtype=T())
-            ops.favor_attention(qkv, pc, o, (RB * W3, so * W3, ss * W3), (RB * inner, so * inner, ss * inner),
+            pcf = pc if gen else self.proj_scaled(log2e=True)
+            ops.favor_attention(qkv, pcf, o, (RB * W3, so * W3, ss * W3), (RB * inner, so * inner, ss * inner),
                                 0, inner, 2 * inner, B, Lo, H, Ls, dh, m, not gen, 1e-3 if gen else 1e-4)
-            ops.linear(o, self.wt("o", self.to_out), _f(self.to_out.bias), out=x_res, residual=x_res)
-            return
+            return ops.linear_residual_ln(o, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln)
         qk = ops.linear(xn, self.wcat("qk", [self.to_q, self.to_k]), None)  # [R, 2*inner]
         # q' [B,Lo,H,Ls,M_PAD]
         dq = torch.empty(B, Lo, H, Ls, M_PAD, device=dev, dtype=T())
@@ -421,7 +425,7 @@ class PerformerSelfAttention(RFModule):
                  c_bs=(RB * H * VT_ROWS, so * H * VT_ROWS, VT_ROWS), c_row=(0, 0, ss * H * VT_ROWS))
         o = torch.empty(R, inner, device=dev, dtype=T())
         ops.linattn_normalize(num, VT_ROWS, o, dh, R * H, dh)
-        ops.linear(o, self.wt("o", self.to_out), _f(self.to_out.bias), out=x_res, residual=x_res)
+        return ops.linear_residual_ln(o, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln)
 
     def forward(self, x):
         """x [S, n, dim] -> [S, n, dim] (library call surface)."""
@@ -455,22 +459,25 @@ class EncoderLayer(RFModule):
         self.ff = Residual(nn.Sequential(nn.LayerNorm(d_msa), FeedForward(d_msa, d_ff, p_dropout=p_dropout),
                                          nn.Dropout(p_dropout)))
 
-    def run(self, x, seq_axis=2, want_att=False):
+    def run(self, x, seq_axis=2, want_att=False, xn=None, next_ln=None):
         """x: fp32 residual stream [B,n1,n2,D], updated in place.  tied: rows = n1 (MSA depth), attention over n2.
-        performer: attention along `seq_axis`."""
-        xn = ln(self.ln, x)
+        performer: attention along `seq_axis`.  xn: self.ln(x) if the previous GEMM already produced it;
+        next_ln: the LayerNorm that will consume x next.  Returns (att, next_ln(x) or None)."""
+        if xn is None:
+            xn = ln(self.ln, x)
         att = None
         if self.tied:
-            att = self.attn.attend(xn, x, want_att)
+            att, xf = self.attn.attend(xn, x, want_att, next_ln=self.ff.fn[0])
         else:
-            self.attn.attend(xn, x, seq_axis)
-        self.ff.fn[1].apply_residual(ln(self.ff.fn[0], x), x)
-        return att
+            xf = self.attn.attend(xn, x, seq_axis, next_ln=self.ff.fn[0])
+        if xf is None:
+            xf = ln(self.ff.fn[0], x)
+        return att, self.ff.fn[1].apply_residual(xf, x, next_ln)
 
     def forward(self, x):
         x = x.detach().float().clone().contiguous()
         if self.tied:
-            att = self.run(x, want_att=self.return_att)
+            att, _ = self.run(x, want_att=self.return_att)
             return (x, att) if self.return_att else x
         # reference flattens (b n) l d: attention along dim 2 of [b, n, l, d]
         self.run(x, seq_axis=2)
@@ -491,12 +498,17 @@ class MsaUpdateUsingSelfAttention(RFModule):
 
     def run(self, x):
         att = None
+        layers = list(self.residue_wise_encoder_layers) + list(self.sequence_wise_encoder_layers)
         n = len(self.residue_wise_encoder_layers)
-        for i, layer in enumerate(self.residue_wise_encoder_layers):
-            a = layer.run(x, want_att=(i == n - 1))  # only the last layer's map is consumed (rf.py:400-401)
-            att = a if a is not None else att
-        for layer in self.sequence_wise_encoder_layers:
-            layer.run(x, seq_axis=1)  # the reference transposes to b l n d: sequences run over the MSA depth
+        xn = None
+        for i, layer in enumerate(layers):
+            nxt = layers[i + 1].ln if i + 1 < len(layers) else None  # the next layer's pre-norm rides in this FF2's epilogue
+            if i < n:
+                a, xn = layer.run(x, want_att=(i == n - 1), xn=xn, next_ln=nxt)  # only the last map is consumed (rf.py:400-401)
+                att = a if a is not None else att
+            else:
+                # the reference transposes to b l n d: sequences run over the MSA depth
+                _, xn = layer.run(x, seq_axis=1, xn=xn, next_ln=nxt)
         return att
 
     def forward(self, x):
@@ -637,10 +649,18 @@ class PairUpdateWithAxialAttentionLayer(RFModule):
             Residual(nn.Sequential(nn.LayerNorm(d_pair), self.ff)),
         )
 
-    def run(self, x):
-        self.row_attn.attend(ln(self.layer[0].fn[0], x), x, axis=1)
-        self.col_attn.attend(ln(self.layer[1].fn[0], x), x, axis=2)
-        self.ff.apply_residual(ln(self.layer[2].fn[0], x), x)
+    def run(self, x, xn=None, next_ln=None):
+        """x fp32 in place; xn = layer[0] pre-norm of x if already produced; returns next_ln(x) or None."""
+        l0, l1, l2 = self.layer[0].fn[0], self.layer[1].fn[0], self.layer[2].fn[0]
+        if xn is None:
+            xn = ln(l0, x)
+        xn = self.row_attn.attend(xn, x, axis=1, next_ln=l1)
+        if xn is None:
+            xn = ln(l1, x)
+        xn = self.col_attn.attend(xn, x, axis=2, next_ln=l2)
+        if xn is None:
+            xn = ln(l2, x)
+        return self.ff.apply_residual(xn, x, next_ln)
 
     def forward(self, x):
         x = x.detach().float().clone().contiguous()
@@ -657,8 +677,10 @@ class PairUpdateWithAxialAttention(RFModule):
                                      for _ in range(n_encoder_layers)])
 
     def run(self, x):
-        for layer in self.layers:
-            layer.run(x)
+        xn = None
+        for i, layer in enumerate(self.layers):
+            nxt = self.layers[i + 1].layer[0].fn[0] if i + 1 < len(self.layers) else None
+            xn = layer.run(x, xn=xn, next_ln=nxt)
 
     def forward(self, x):
         x = x.detach().float().clone().contiguous()
@@ -697,21 +719,24 @@ class MsaUpdateWithPairLayer(RFModule):
         b = lin.weight.detach().float() @ lnm.bias.detach().float() + lin.bias.detach().float()
         return w, b
 
-    def run(self, msa, att):
-        """msa fp32 [B,N,L,D] in place; att: T [H,B,L,L] (softmax over the last dim)."""
+    def run(self, msa, att, xn=None, next_ln=None):
+        """msa fp32 [B,N,L,D] in place; att: T [H,B,L,L] (softmax over the last dim); xn = msa2value pre-norm if the
+        previous GEMM produced it; returns next_ln(msa) or None."""
         B, N, Lr, D = msa.shape
         H = self.n_heads
         dv = D // H
         v_t = torch.empty(B, N, D, Lr, device=msa.device, dtype=T())
         lin = self.msa2value[1]
-        ops.gemm(self.wt("v", lin), ln(self.msa2value[0], msa), v_t, D, Lr, D, batch=(B * N, 1, 1), b_bs=(Lr * D, 0, 0),
+        if xn is None:
+            xn = ln(self.msa2value[0], msa)
+        ops.gemm(self.wt("v", lin), xn, v_t, D, Lr, D, batch=(B * N, 1, 1), b_bs=(Lr * D, 0, 0),
                  c_bs=(D * Lr, 0, 0), c_row=(0, 0, Lr), bias=_f(lin.bias), bias_mode=L.BIAS_ROW)
         # msa += att @ v  (rf.py:592-595), scattered back to [b,n,i,(h,d)]
         ops.gemm(att, v_t, msa, Lr, N * dv, Lr, batch=(H, B, 1),
                  a_bs=(B * Lr * Lr, Lr * Lr, 0), a_row=(0, 0, Lr),
                  b_bs=(dv * Lr, N * D * Lr, 0), b_row=(dv, D * Lr, Lr),
                  c_bs=(dv, N * Lr * D, 0), c_row=(0, 0, D), c_col=(dv, Lr * D), residual=msa)
-        self.ff.fn[1].apply_residual(ln(self.ff.fn[0], msa), msa)
+        return self.ff.fn[1].apply_residual(ln(self.ff.fn[0], msa), msa, next_ln)
 
 
 def pair_to_att(layers, pair):
@@ -749,9 +774,12 @@ class MsaUpdateWithPair(RFModule):
                                              for _ in range(n_encoder_layers)])
 
     def run(self, msa, pair):
-        atts = pair_to_att(list(self.encoder_layers), pair)
-        for layer, att in zip(self.encoder_layers, atts):
-            layer.run(msa, att)
+        layers = list(self.encoder_layers)
+        atts = pair_to_att(layers, pair)
+        xn = None
+        for i, (layer, att) in enumerate(zip(layers, atts)):
+            nxt = layers[i + 1].msa2value[0] if i + 1 < len(layers) else None
+            xn = layer.run(msa, att, xn=xn, next_ln=nxt)
 
     def forward(self, msa, pair):
         msa = msa.detach().float().clone().contiguous()

@@ -47,7 +47,7 @@ def gemm(A, B, Cout, M, N, K, *, batch=(1, 1, 1), a_off=0, b_off=0, c_off=0,
          b_bs=(0, 0, 0), b_row=(0, 0, None), b_ko=0, kc=0,
          c_bs=(0, 0, 0), c_row=(0, 0, None), c_col=(0, 0),
          bias=None, bias_mode=None, act=L.ACT_NONE, act_nvalid=0, act_eps=0.0, alpha=1.0,
-         residual=None, res_off=None, conv=None, tile_cfg=0):
+         residual=None, res_off=None, conv=None, tile_cfg=0, ln=None):
     """C = epilogue(alpha * A @ B^T) with the strided/batched/chunked addressing of rf_gemm_desc.
     *_row = (rc, ro, ri): offset(m) = (m // rc)*ro + (m % rc)*ri, rc=0 -> m*ri.  ri=None -> K (A,B) / N (C).
     c_col = (cc, co).  Offsets are in elements.  conv = (n, h, w, c, dilation) selects implicit 3x3 im2col."""
@@ -83,11 +83,15 @@ def gemm(A, B, Cout, M, N, K, *, batch=(1, 1, 1), a_off=0, b_off=0, c_off=0,
         if residual.dtype != F32:
             raise TypeError("residual must be fp32")
         d.residual = residual.data_ptr() + (c_off if res_off is None else res_off) * 4
+    if ln is not None:  # (out bf16 [M,N], gamma, beta, eps): fused LayerNorm of the result rows
+        ln_out, g, b, eps = ln
+        _need_cuda(ln_out, g, b)
+        d.ln_out, d.ln_gamma, d.ln_beta, d.ln_eps = ln_out.data_ptr(), g.data_ptr(), b.data_ptr(), float(eps)
     check(lib.rf_gemm(C.byref(d), stream()), "rf_gemm")
     return Cout
 
 
-def linear(x, w, bias=None, *, out=None, out_dtype=None, act=L.ACT_NONE, residual=None, alpha=1.0, tile_cfg=0):
+def linear(x, w, bias=None, *, out=None, out_dtype=None, act=L.ACT_NONE, residual=None, alpha=1.0, tile_cfg=0, ln=None):
     """out[..., N] = act(x[..., K] @ w[N, K]^T + bias) (+ residual).  x contiguous, w [N, Kw>=K] contiguous."""
     K = x.shape[-1]
     Mrows = x.numel() // K
@@ -96,7 +100,7 @@ def linear(x, w, bias=None, *, out=None, out_dtype=None, act=L.ACT_NONE, residua
         raise ValueError(f"linear: K mismatch {w.shape} vs {x.shape}")
     if out is None:
         out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=out_dtype or x.dtype)
-    gemm(x, w, out, Mrows, N, K, bias=bias, act=act, residual=residual, alpha=alpha, tile_cfg=tile_cfg)
+    gemm(x, w, out, Mrows, N, K, bias=bias, act=act, residual=residual, alpha=alpha, tile_cfg=tile_cfg, ln=ln)
     return out
 
 
@@ -336,3 +340,22 @@ def favor_attention(qkv, pc, out, x_strides, o_strides, q_off, k_off, v_off, n_b
                                  n_h, seq_len, dim_head, n_features, 1 if softmax_kernel else 0, eps, stream()),
           "rf_favor_attention")
     return out
+
+
+# Measured on MI355X (tools/ln_fuse_bench.py): the fused epilogue costs more than residual GEMM + the vectorised
+# rf_layernorm (0.50 vs 0.37 ms at M=262144, N=288, K=512), so it is opt-in.
+FUSE_LN = False
+
+
+def linear_residual_ln(x, w, bias, x_res, next_ln):
+    """x_res += x @ w^T + bias (fp32, in place).  If `next_ln` (an nn.LayerNorm) is given and the fused epilogue applies
+    (bf16 operands, full rows per tile), also returns LayerNorm_next(x_res) in bf16; otherwise returns None and the
+    caller normalises with rf_layernorm."""
+    N = w.shape[0]
+    if FUSE_LN and next_ln is not None and x.dtype == BF16 and N <= 384 and N % 4 == 0 and x_res.is_contiguous():
+        xn = torch.empty(x_res.shape, device=x_res.device, dtype=BF16)
+        linear(x, w, bias, out=x_res, residual=x_res,
+               ln=(xn, next_ln.weight.detach(), next_ln.bias.detach(), next_ln.eps))
+        return xn
+    linear(x, w, bias, out=x_res, residual=x_res)
+    return None

@@ -39,12 +39,35 @@ def test_linear(dtype, tol, M, N, K):
     assert rel_err(y, torch.relu(ref) + res) < tol
 
 
-@pytest.mark.parametrize("cfg", list(range(1, 24)))
+@pytest.mark.parametrize("cfg", list(range(1, 25)))
 def test_gemm_all_tile_configs(cfg):
     M, N, K = 777, 600, 352
     x, w = randn(M, K, dtype=torch.bfloat16), randn(N, K, dtype=torch.bfloat16, seed=1)
     y = ops.linear(x, w, None, out_dtype=torch.float32, tile_cfg=cfg)
     assert rel_err(y, x.float() @ w.float().t()) < 1e-2
+
+
+@pytest.mark.parametrize("N,K", [(288, 512), (288, 1152), (384, 768), (96, 64)])
+def test_gemm_fused_residual_layernorm(N, K):
+    """C = residual + x W^T + b with the NEXT LayerNorm fused into the epilogue (bf16 path)."""
+    import torch.nn as nn
+    M = 1000
+    x, w, b = randn(M, K, dtype=torch.bfloat16), randn(N, K, dtype=torch.bfloat16, seed=1) * 0.1, randn(N, seed=2)
+    res = randn(M, N, seed=3) * 2 + 0.5
+    lnm = nn.LayerNorm(N).to(DEV)
+    with torch.no_grad():
+        lnm.weight.copy_(randn(N, seed=4)); lnm.bias.copy_(randn(N, seed=5))
+    ref = res + x.float() @ w.float().t() + b
+    ref_ln = torch.nn.functional.layer_norm(ref, (N,), lnm.weight, lnm.bias, lnm.eps)
+    out = res.clone()
+    ops.FUSE_LN = True
+    try:
+        xn = ops.linear_residual_ln(x, w, b, out, lnm)
+    finally:
+        ops.FUSE_LN = False
+    assert xn is not None and xn.dtype == torch.bfloat16
+    assert rel_err(out, ref) < 2e-2
+    assert rel_err(xn, ref_ln) < 3e-2
 
 
 def test_gemm_exact_integers_layout():
