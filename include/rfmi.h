@@ -170,7 +170,8 @@ int rf_favor_softmax_features(const void* dash, const void* x, const int64_t xs[
  * entirely on-chip.  qkv: bf16 rows holding q|k|v at column offsets q_off/k_off/v_off (+ h*dim_head); the row of
  * (b,o,s) starts at b*x_strides[0] + o*x_strides[1] + s*x_strides[2] (elements); out (bf16) likewise with o_strides,
  * head h at column h*dim_head.  pc: bf16 [288][64] projection matrix pre-scaled by dim_head^-1/4, rows >= 266 zero.
- * Supported: dim_head 64, n_features 266, seq_len 128 or 256 (other shapes: use the unfused chain of rf_gemm +
+ * Supported: dim_head 64, n_features 266, seq_len 64/128/256, and (ReLU kernel) any multiple of 256 walked in 256-row
+ * chunks -- the L=1024 configuration (other shapes: use the unfused chain of rf_gemm +
  * rf_favor_softmax_features + rf_linattn_normalize).  softmax_kernel != 0: exp features with the library's
  * stabilisers (per-row max for q, per-(b,o,h) max for k) and eps; else relu(x)+eps. */
 int rf_favor_attention(const void* qkv, const void* pc, void* out, const int64_t x_strides[3],

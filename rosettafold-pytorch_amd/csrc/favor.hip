@@ -18,6 +18,8 @@
 //   B2: num[d,s] += ctx[m,d] q'[m,s]        A = ctx^T (LDS, bf16), B = q' (from B1's accumulators)
 // Phase A splits the 17 feature tiles (266 features) over the 4 waves, phase B splits the sequence.
 // K and V of the NEXT item are DMA-prefetched (global_load_lds) while phase B runs.
+#include <type_traits>
+
 #include "common.h"
 
 #define FV_DH 64
@@ -25,6 +27,8 @@
 #define FV_MT 17        // feature tiles of 16 that contain valid features
 #define FV_MPAD 288
 #define FV_CTX_LD 592   // bytes per ctx^T row (288 bf16 + pad: conflict-free ds_read_b64)
+#define FV_DT 5         // value tiles: 4 x 16 head dims + the ones column (d = 64) that yields sum_s k' and the denominator
+#define FV_DROWS 80
 
 struct FavorAttnP {
   const bf16_t* qkv;  // [.., 3*inner] rows; q | k | v
@@ -34,6 +38,7 @@ struct FavorAttnP {
   int64_t o_b, o_o, o_s;  // same for out
   int q_off, k_off, v_off;
   int n_o, n_h, nitems;
+  int nchunks;  // sequence = nchunks * LS rows (ReLU kernel only; softmax kernel: 1)
   float eps;
 };
 
@@ -75,8 +80,7 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
   constexpr int K_OFF = FV_MPAD * 128;
   constexpr int V_OFF = K_OFF + LS * 128;
   constexpr int CTX_OFF = V_OFF + LS * 128;
-  constexpr int KSUM_OFF = CTX_OFF + FV_DH * FV_CTX_LD;
-  constexpr int DIAG_OFF = KSUM_OFF + FV_MPAD * 4;
+  constexpr int DIAG_OFF = CTX_OFF + FV_DROWS * FV_CTX_LD;
   constexpr int RED_OFF = DIAG_OFF + LS * 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -85,11 +89,16 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
   // this wave's feature tiles in phase A: 5,4,4,4
   const int nm = wave == 0 ? 5 : 4;
   const int m0t = wave == 0 ? 0 : 5 + 4 * (wave - 1);
+  const f32x4 epsv = {p.eps, p.eps, p.eps, p.eps};
+  // "ones column": value column d = 64 is identically 1, so ctx^T row 64 = sum_s k' (the normaliser's k' sums) and
+  // the numerator tile of d-tile 4 carries the denominator in its row 64 -- both ride on the MFMA pipe.
+  Frag ones;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ones.u[k] = fr == 0 ? 0x3F803F80u : 0u;
 
   // one-time: projection image, zeroed ctx^T (its padded columns are read as MFMA operands)
   fv_load_tile(smem, PC_OFF, p.pc, FV_DH, FV_MPAD, wave, lane);
-  for (int i = tid; i < FV_DH * FV_CTX_LD / 4; i += 256) ((unsigned*)(smem + CTX_OFF))[i] = 0u;
-  for (int i = tid; i < FV_MPAD; i += 256) ((float*)(smem + KSUM_OFF))[i] = 0.f;
+  for (int i = tid; i < FV_DROWS * FV_CTX_LD / 4; i += 256) ((unsigned*)(smem + CTX_OFF))[i] = 0u;
 
   auto item_base = [&](int item, int64_t& xb, int64_t& ob) {
     const int h = item % p.n_h;
@@ -99,6 +108,7 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
     ob = (int64_t)b * p.o_b + (int64_t)o * p.o_o + h * FV_DH;
   };
 
+  const int nch = p.nchunks;  // > 1: long sequence walked in LS-row chunks (no cross-item prefetch then)
   int item = blockIdx.x;
   if (item < p.nitems) {
     int64_t xb, ob;
@@ -113,17 +123,20 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
     __syncthreads();  // K, V (and Pc on the first item) have landed; previous item fully consumed
     // Q fragments of this wave's rows straight from global; consumed in phase B, so phase A hides the latency
     bf16x8 qf[ST][2];
+    auto load_q = [&](int chunk) {
 #pragma unroll
-    for (int t = 0; t < ST; ++t) {
-      const int s = (wave * ST + t) * 16 + fr;
-      const bf16_t* qrow = p.qkv + xb + p.q_off + (int64_t)s * p.x_s;
+      for (int t = 0; t < ST; ++t) {
+        const int s = chunk * LS + (wave * ST + t) * 16 + fr;
+        const bf16_t* qrow = p.qkv + xb + p.q_off + (int64_t)s * p.x_s;
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) qf[t][kk] = *(const bf16x8*)(qrow + (kk * 4 + fq) * 8);
-    }
+        for (int kk = 0; kk < 2; ++kk) qf[t][kk] = *(const bf16x8*)(qrow + (kk * 4 + fq) * 8);
+      }
+    };
+    load_q(0);
 
     float gmax = 0.f;
     if constexpr (SOFTMAX) {
-      // diag_k[s] = |k_s|^2 / (2 sqrt(d)); one row per thread
+      // diag_k[s] = |k_s|^2 / (2 sqrt(d)) in log2 units (Pc carries log2 e); one row per thread
       for (int s = tid; s < LS; s += 256) {
         float a = 0.f;
 #pragma unroll
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
             a = fmaf(f, f, a);
           }
         }
-        ((float*)(smem + DIAG_OFF))[s] = a * (0.0625f * 1.4426950408889634f);  // log2 units (Pc carries log2 e)
+        ((float*)(smem + DIAG_OFF))[s] = a * (0.0625f * 1.4426950408889634f);
       }
     }
 
@@ -178,13 +191,18 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
       gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     }
 
-    f32x4 ctx[5][4];
-    float ksum_p[5];
+    f32x4 ctx[5][FV_DT];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      ksum_p[j] = 0.f;
+    for (int j = 0; j < 5; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ctx[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < FV_DT; ++i) ctx[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ck = 0; ck < nch; ++ck) {
+    if (ck > 0) {  // next LS-row chunk of K and V (everyone is done with the previous one)
+      __syncthreads();
+      fv_load_tile(smem, K_OFF, p.qkv + xb + p.k_off + (int64_t)ck * LS * p.x_s, p.x_s, LS, wave, lane);
+      fv_load_tile(smem, V_OFF, p.qkv + xb + p.v_off + (int64_t)ck * LS * p.x_s, p.x_s, LS, wave, lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
     }
     for (int u = 0; u < NSB; ++u) {
       bf16x8 kf[2][2];
@@ -208,12 +226,13 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
           }
         }
       }
-      float dg[2][4];
+      // accumulator init carries the additive terms: +eps (ReLU kernel) or -(diag + max) (softmax kernel, log2 units)
+      f32x4 init[2] = {epsv, epsv};
       if constexpr (SOFTMAX) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const float4 d4 = *(const float4*)(smem + DIAG_OFF + ((2 * u + t) * 16 + 4 * fq) * 4);
-          dg[t][0] = d4.x + gmax; dg[t][1] = d4.y + gmax; dg[t][2] = d4.z + gmax; dg[t][3] = d4.w + gmax;
+          init[t] = (f32x4){-(d4.x + gmax), -(d4.y + gmax), -(d4.z + gmax), -(d4.w + gmax)};
         }
       }
 #pragma unroll
@@ -222,32 +241,26 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
           f32x4 a[2];
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            a[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            a[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], pf[j][0], a[t], 0, 0, 0);
+            a[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], pf[j][0], init[t], 0, 0, 0);
             a[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], pf[j][1], a[t], 0, 0, 0);
           }
-          // only feature tile 16 (m = 256..271) holds padded features: mask there, nowhere else
-          const bool last_tile = (m0t + j) == FV_MT - 1;
-          const bool valid = !last_tile || fr < FV_M - 16 * (FV_MT - 1);
           float f[2][4];
 #pragma unroll
           for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float x;
               if constexpr (SOFTMAX)
-                x = __builtin_amdgcn_exp2f(a[t][r] - dg[t][r]) + p.eps;  // dg already holds diag + max (log2 units)
+                f[t][r] = __builtin_amdgcn_exp2f(a[t][r]) + p.eps;
               else
-                x = fmaxf(a[t][r] + p.eps, p.eps);
-              f[t][r] = x;
+                f[t][r] = fmaxf(a[t][r], p.eps);  // relu(x) + eps with eps folded into the accumulator
             }
-          if (last_tile && !valid) {
+          // only feature tile 16 (m = 256..271) holds padded features: mask there, nowhere else (wave-uniform branch)
+          if ((m0t + j) == FV_MT - 1 && fr >= FV_M - 16 * (FV_MT - 1)) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
               for (int r = 0; r < 4; ++r) f[t][r] = 0.f;
           }
-          ksum_p[j] += ((f[0][0] + f[0][1]) + (f[0][2] + f[0][3])) + ((f[1][0] + f[1][1]) + (f[1][2] + f[1][3]));
           Frag kfr;
           kfr.u[0] = pack2(f[0][0], f[0][1]);
           kfr.u[1] = pack2(f[0][2], f[0][3]);
@@ -256,34 +269,32 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             ctx[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr.v, vf[i].v, ctx[j][i], 0, 0, 0);
+          ctx[j][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr.v, ones.v, ctx[j][4], 0, 0, 0);
         }
       }
     }
-    // publish ctx^T (bf16) and ksum
+    }  // chunks of K / V
+    // publish ctx^T (bf16), rows 0..63 = values, row 64 = k' sums
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       if (j < nm) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < FV_DT; ++i) {
           uint2 w;
           w.x = pack2(ctx[j][i][0], ctx[j][i][1]);
           w.y = pack2(ctx[j][i][2], ctx[j][i][3]);
           *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ((m0t + j) * 16 + 4 * fq) * 2) = w;
         }
-        float s = ksum_p[j];
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (fq == 0) ((float*)(smem + KSUM_OFF))[(m0t + j) * 16 + fr] = s;
       }
     }
-    __syncthreads();  // ctx^T / ksum visible; K and V tiles are free again
+    __syncthreads();  // ctx^T visible; K and V tiles are free again
 
     // prefetch the next item's K and V while phase B runs.  The Q loads issued before phase A are drained first so
     // the compiler's wait at their first use cannot turn into a wait for these DMAs.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     {
       const int nxt = item + gridDim.x;
-      if (nxt < p.nitems) {
+      if (nxt < p.nitems) {  // (with nch > 1 K/V hold the LAST chunk of this item: also free now)
         int64_t xb2, ob2;
         item_base(nxt, xb2, ob2);
         fv_load_tile(smem, K_OFF, p.qkv + xb2 + p.k_off, p.x_s, LS, wave, lane);
@@ -292,8 +303,11 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
     }
 
     // ---------------- phase B ----------------
-    float dq[ST], rmax[ST];
+    f32x4 qinit[ST];
+#pragma unroll
+    for (int t = 0; t < ST; ++t) qinit[t] = epsv;
     if constexpr (SOFTMAX) {
+      float dq[ST], rmax[ST];
 #pragma unroll
       for (int t = 0; t < ST; ++t) {
         float a = 0.f;
@@ -328,56 +342,53 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
       for (int t = 0; t < ST; ++t) {
         rmax[t] = fmaxf(rmax[t], __shfl_xor(rmax[t], 16, 64));
         rmax[t] = fmaxf(rmax[t], __shfl_xor(rmax[t], 32, 64));
+        const float off = -(dq[t] + rmax[t]);
+        qinit[t] = (f32x4){off, off, off, off};
       }
     }
-    f32x4 num[4][ST];
-    float den[ST];
+    for (int qc = 0; qc < nch; ++qc) {
+    if (qc > 0) load_q(qc);
+    f32x4 num[FV_DT][ST];
 #pragma unroll
-    for (int t = 0; t < ST; ++t) {
-      den[t] = 0.f;
+    for (int t = 0; t < ST; ++t)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) num[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    for (int u = 0; u < FV_MPAD / 32; ++u) {
+      for (int i = 0; i < FV_DT; ++i) num[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // one m-block (two feature tiles 2u, 2u+1): q' features -> B fragments -> num += ctx^T q'
+    auto mblock = [&](int u, auto last_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;  // u == 8: tile 16 is partly padded, tile 17 is all padding
       float f[2][ST][4];
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
-        const int j = 2 * u + jj;
-        if (j < FV_MT) {
-          bf16x8 pfr[2];
-#pragma unroll
-          for (int kk = 0; kk < 2; ++kk) pfr[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off(j * 16 + fr, kk * 4 + fq));
-          const float4 ks = *(const float4*)(smem + KSUM_OFF + (j * 16 + 4 * fq) * 4);
-          const float ksv[4] = {ks.x, ks.y, ks.z, ks.w};
-#pragma unroll
-          for (int t = 0; t < ST; ++t) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[0], qf[t][0], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[1], qf[t][1], a, 0, 0, 0);
-            float off = 0.f;
-            if constexpr (SOFTMAX) off = dq[t] + rmax[t];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float x;
-              if constexpr (SOFTMAX)
-                x = __builtin_amdgcn_exp2f(a[r] - off) + p.eps;
-              else
-                x = fmaxf(a[r] + p.eps, p.eps);
-              if (j == FV_MT - 1 && 4 * fq + r >= FV_M - 16 * (FV_MT - 1)) x = 0.f;
-              f[jj][t][r] = x;
-              den[t] = fmaf(x, ksv[r], den[t]);
-            }
-          }
-        } else {
+        if (LAST && jj == 1) {
 #pragma unroll
           for (int t = 0; t < ST; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) f[jj][t][r] = 0.f;
+        } else {
+          const int j = 2 * u + jj;
+          bf16x8 pfr[2];
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) pfr[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off(j * 16 + fr, kk * 4 + fq));
+#pragma unroll
+          for (int t = 0; t < ST; ++t) {
+            f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[0], qf[t][0], qinit[t], 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[1], qf[t][1], a, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x;
+              if constexpr (SOFTMAX)
+                x = __builtin_amdgcn_exp2f(a[r]) + p.eps;
+              else
+                x = fmaxf(a[r], p.eps);
+              if (LAST && 4 * fq + r >= FV_M - 16 * (FV_MT - 1)) x = 0.f;
+              f[jj][t][r] = x;
+            }
+          }
         }
       }
-      Frag cf[4];
+      Frag cf[FV_DT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < FV_DT; ++i) {
         const char* base = smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + (32 * u + 4 * fq) * 2;
         cf[i].h[0] = *(const uint2*)base;
         cf[i].h[1] = *(const uint2*)(base + 32);
@@ -390,18 +401,18 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
         qfr.u[2] = pack2(f[1][t][0], f[1][t][1]);
         qfr.u[3] = pack2(f[1][t][2], f[1][t][3]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FV_DT; ++i)
           num[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[i].v, qfr.v, num[i][t], 0, 0, 0);
       }
-    }
-    // epilogue: out[s][h*64 + d] = num / den; lane owns 4 consecutive d of row s
+    };
+    for (int u = 0; u < (FV_MT - 1) / 2; ++u) mblock(u, std::false_type{});
+    mblock((FV_MT - 1) / 2, std::true_type{});
+    // epilogue: out[s][h*64 + d] = num[d][s] / num[64][s]; lane owns 4 consecutive d of row s
 #pragma unroll
     for (int t = 0; t < ST; ++t) {
-      float dn = den[t];
-      dn += __shfl_xor(dn, 16, 64);
-      dn += __shfl_xor(dn, 32, 64);
+      const float dn = __shfl(num[4][t][0], fr, 64);  // row d = 64 lives in register 0 of the fq == 0 lanes
       const float inv = 1.f / dn;
-      const int s = (wave * ST + t) * 16 + fr;
+      const int s = qc * LS + (wave * ST + t) * 16 + fr;
       bf16_t* orow = p.out + ob + (int64_t)s * p.o_s;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -411,12 +422,13 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
         *(uint2*)(orow + i * 16 + 4 * fq) = w;
       }
     }
+    }  // chunks of Q
   }
 }
 
 template <int LS, bool SM>
 static int launch_favor(const FavorAttnP& p, hipStream_t s) {
-  const size_t lds = (size_t)FV_MPAD * 128 + 2 * (size_t)LS * 128 + (size_t)FV_DH * FV_CTX_LD + FV_MPAD * 4 + LS * 4 + 64;
+  const size_t lds = (size_t)FV_MPAD * 128 + 2 * (size_t)LS * 128 + (size_t)FV_DROWS * FV_CTX_LD + LS * 4 + 64;
   auto k = favor_attention_kernel<LS, SM>;
   static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
@@ -431,7 +443,13 @@ extern "C" int rf_favor_attention(const void* qkv, const void* pc, void* out, co
                                   int n_h, int seq_len, int dim_head, int n_features, int softmax_kernel, float eps,
                                   void* stream) {
   if (dim_head != FV_DH || n_features != FV_M) return RF_EINVAL;
-  if (seq_len != 128 && seq_len != 256) return RF_EINVAL;
+  int nchunks = 1, ls = seq_len;
+  if (seq_len > 256) {  // long sequences: 256-row chunks (ReLU kernel; the softmax kernel needs the global key max first)
+    if (softmax_kernel || seq_len % 256) return RF_EINVAL;
+    nchunks = seq_len / 256;
+    ls = 256;
+  }
+  if (ls != 64 && ls != 128 && ls != 256) return RF_EINVAL;
   if (((uintptr_t)qkv % 16) || ((uintptr_t)pc % 16) || ((uintptr_t)out % 8)) return RF_EALIGN;
   for (int i = 0; i < 3; ++i)
     if (x_strides[i] % 8 || o_strides[i] % 4) return RF_EALIGN;
@@ -446,7 +464,9 @@ extern "C" int rf_favor_attention(const void* qkv, const void* pc, void* out, co
   p.n_o = n_o; p.n_h = n_h;
   p.nitems = n_b * n_o * n_h;
   p.eps = eps;
+  p.nchunks = nchunks;
   hipStream_t s = (hipStream_t)stream;
-  if (seq_len == 256) return softmax_kernel ? launch_favor<256, true>(p, s) : launch_favor<256, false>(p, s);
-  return softmax_kernel ? launch_favor<128, true>(p, s) : launch_favor<128, false>(p, s);
+  if (ls == 256) return softmax_kernel ? launch_favor<256, true>(p, s) : launch_favor<256, false>(p, s);
+  if (ls == 128) return softmax_kernel ? launch_favor<128, true>(p, s) : launch_favor<128, false>(p, s);
+  return softmax_kernel ? launch_favor<64, true>(p, s) : launch_favor<64, false>(p, s);
 }

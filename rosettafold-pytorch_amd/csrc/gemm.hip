@@ -494,11 +494,15 @@ __device__ __forceinline__ float a_elem_f32(const rf_gemm_desc& d, const float* 
 }
 
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
+  // Exact fp32: v_mfma_f32_16x16x4_f32 is bit-for-bit a k-ordered fmaf chain (no reduced-precision inputs), at the
+  // fp32 matrix rate.  64x64 tile, BK=16, 4 waves x (32x32 = 2x2 MFMA tiles); generic (strided / conv) operand loads.
   constexpr int BM = 64, BN = 64, BK = 16;
   __shared__ float As[BK][BM + 4];
   __shared__ float Bs[BK][BN + 4];
   const rf_gemm_desc& d = p.d;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int wr = wave >> 1, wc = wave & 1;
   const int lid = blockIdx.x;
   const int tn = lid % p.tilesN;
   const int t2 = lid / p.tilesN;
@@ -509,10 +513,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
   const int m0 = tm * BM, n0 = tn * BN;
   const float* Ab = (const float*)d.A + (d.a_mode == RF_AMODE_CONV3X3 ? 0 : z0 * d.a_bs[0] + z1 * d.a_bs[1] + z2 * d.a_bs[2]);
   const float* Bb = (const float*)d.B + z0 * d.b_bs[0] + z1 * d.b_bs[1] + z2 * d.b_bs[2];
-  const int tx = tid & 15, ty = tid >> 4;  // thread owns rows ty*4.., cols tx*4..
-  float acc[4][4] = {};
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < d.K; k0 += BK) {
-    // 64 rows x 16 k per operand = 1024 elements, 4 per thread; k fastest for coalescing
     for (int e = tid; e < BM * BK; e += 256) {
       const int r = e / BK, kk = e % BK;
       As[kk][r] = a_elem_f32(d, Ab, m0 + r, k0 + kk);
@@ -523,34 +529,41 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < BK; ++kk) {
-      float a[4], b[4];
+    for (int g = 0; g < BK / 4; ++g) {
+      float af[2], bf[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+      for (int i = 0; i < 2; ++i) af[i] = As[4 * g + fq][wr * 32 + i * 16 + fr];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+      for (int j = 0; j < 2; ++j) bf[j] = Bs[4 * g + fq][wc * 32 + j * 16 + fr];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j)
+          // weights as MFMA-A, activations as MFMA-B: D[n_local = 4q+r][m_local = lane&15]
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
   const int64_t c_z = z0 * d.c_bs[0] + z1 * d.c_bs[1] + z2 * d.c_bs[2];
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wr * 32 + i * 16 + fr;
     if (m >= d.M) continue;
     const int64_t c_row = c_z + split_off(m, d.c_rc, d.c_ro, d.c_ri);
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx * 4 + j;
-      if (n >= d.N) continue;
-      float x = acc[i][j] * d.alpha;
-      if (d.bias_mode == RF_BIAS_COL) x += d.bias[n];
-      if (d.bias_mode == RF_BIAS_ROW) x += d.bias[m];
-      x = apply_act(x, d.act, d.act_eps, (d.act_nvalid < 0 ? m < -d.act_nvalid : n < d.act_nvalid));
-      const int64_t o = c_row + split_off(n, d.c_cc, d.c_co, 1);
-      if (d.residual) x += d.residual[o];
-      st(d.C, d.c_dtype, o, x);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wc * 32 + j * 16 + 4 * fq + r;
+        if (n >= d.N) continue;
+        float x = acc[i][j][r] * d.alpha;
+        if (d.bias_mode == RF_BIAS_COL) x += d.bias[n];
+        if (d.bias_mode == RF_BIAS_ROW) x += d.bias[m];
+        x = apply_act(x, d.act, d.act_eps, (d.act_nvalid < 0 ? m < -d.act_nvalid : n < d.act_nvalid));
+        const int64_t o = c_row + split_off(n, d.c_cc, d.c_co, 1);
+        if (d.residual) x += d.residual[o];
+        st(d.C, d.c_dtype, o, x);
+      }
     }
   }
 }

@@ -360,8 +360,103 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const void* x, int 
   }
 }
 
+// ---- vectorised fast paths (x bf16 NHWC, C % 8 == 0): 16-byte loads, 8 channels per thread -------------------
+#define INV_PIX 1024  // pixels per block in the vectorised statistics kernel
+__global__ __launch_bounds__(256) void instnorm_stats_vec_kernel(const bf16_t* x, double* sums, int64_t HW, int C) {
+  extern __shared__ float sm[];  // [2][C]
+  const int b = blockIdx.y;
+  const int nch = C >> 3;
+  const int ppi = 256 / nch;  // pixels handled per iteration
+  for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  const int64_t p0 = (int64_t)blockIdx.x * INV_PIX;
+  const int64_t p1 = p0 + INV_PIX < HW ? p0 + INV_PIX : HW;
+  const int ch = threadIdx.x % nch, po = threadIdx.x / nch;
+  if (po < ppi) {
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    for (int64_t p = p0 + po; p < p1; p += ppi) {
+      const bf16x8 v = *(const bf16x8*)(x + ((int64_t)b * HW + p) * C + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = bf2f((bf16_t)v[e]);
+        s[e] += f;
+        q[e] = fmaf(f, f, q[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      atomicAdd(&sm[ch * 8 + e], s[e]);
+      atomicAdd(&sm[C + ch * 8 + e], q[e]);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(&sums[((int64_t)b * C + c) * 2 + 0], (double)sm[c]);
+    atomicAdd(&sums[((int64_t)b * C + c) * 2 + 1], (double)sm[C + c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void instnorm_apply_vec_kernel(const bf16_t* x, const double* sums, const float* gamma,
+                                                                 const float* beta, float eps, const float* residual,
+                                                                 int act, void* y, int y_dt, void* y2, int y2_dt,
+                                                                 int64_t HW, int C) {
+  extern __shared__ float sm[];  // scale[C], shift[C]
+  const int b = blockIdx.y;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double s = sums[((int64_t)b * C + c) * 2], q = sums[((int64_t)b * C + c) * 2 + 1];
+    const double mean = s / (double)HW;
+    double var = q / (double)HW - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float sc = rsqrtf((float)var + eps) * gamma[c];
+    sm[c] = sc;
+    sm[C + c] = beta[c] - (float)mean * sc;
+  }
+  __syncthreads();
+  const int nch = C >> 3;
+  const int64_t nchunks = HW * nch;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nchunks; idx += (int64_t)gridDim.x * 256) {
+    const int ch = idx % nch;
+    const int64_t e0 = ((int64_t)b * HW) * C + idx * 8;  // idx = pixel*nch + ch -> element offset pixel*C + ch*8
+    const bf16x8 v = *(const bf16x8*)(x + e0);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = bf2f((bf16_t)v[e]) * sm[ch * 8 + e] + sm[C + ch * 8 + e];
+    if (residual) {
+      const float4 r0 = *(const float4*)(residual + e0), r1 = *(const float4*)(residual + e0 + 4);
+      o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w;
+      o[4] += r1.x; o[5] += r1.y; o[6] += r1.z; o[7] += r1.w;
+    }
+    if (act == RF_ACT_ELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = o[e] > 0.f ? o[e] : __expf(o[e]) - 1.f;
+    }
+    auto put = [&](void* dst, int dt) {
+      if (dt == RF_F32) {
+        *(float4*)((float*)dst + e0) = make_float4(o[0], o[1], o[2], o[3]);
+        *(float4*)((float*)dst + e0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      } else {
+        uint4 w;
+        w.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+        w.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+        w.z = (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16);
+        w.w = (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16);
+        *(uint4*)((bf16_t*)dst + e0) = w;
+      }
+    };
+    put(y, y_dt);
+    if (y2) put(y2, y2_dt);
+  }
+}
+
 extern "C" int rf_instnorm_stats(const void* x, int x_dtype, void* sums, int B, int64_t HW, int C, void* stream) {
   RF_CHECK_DT(x_dtype);
+  if (x_dtype == RF_BF16 && C % 8 == 0 && C / 8 <= 256 && ((uintptr_t)x % 16) == 0) {
+    hipLaunchKernelGGL(instnorm_stats_vec_kernel, dim3(cdiv(HW, INV_PIX), B), dim3(256), 2 * C * sizeof(float),
+                       (hipStream_t)stream, (const bf16_t*)x, (double*)sums, HW, C);
+    return rf_launch_status();
+  }
   hipLaunchKernelGGL(instnorm_stats_kernel, dim3(cdiv(HW, IN_PIX), B), dim3(256), 0, (hipStream_t)stream, x, x_dtype,
                      (double*)sums, HW, C);
   return rf_launch_status();
@@ -393,6 +488,14 @@ extern "C" int rf_instnorm_apply(const void* x, int x_dtype, const void* sums, c
   RF_CHECK_DT(x_dtype);
   RF_CHECK_DT(y_dtype);
   const int64_t total = (int64_t)B * HW * C;
+  if (x_dtype == RF_BF16 && C % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+      (!y2 || ((uintptr_t)y2 % 16) == 0) && (!residual || ((uintptr_t)residual % 16) == 0)) {
+    const unsigned gx = min(cdiv(HW * (C / 8), 256), 4096u);
+    hipLaunchKernelGGL(instnorm_apply_vec_kernel, dim3(gx, B), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
+                       (const bf16_t*)x, (const double*)sums, gamma, beta, eps, residual, act, y, y_dtype, y2, y2_dtype,
+                       HW, C);
+    return rf_launch_status();
+  }
   hipLaunchKernelGGL(instnorm_apply_kernel, dim3(min(cdiv(total, 256), 16384u)), dim3(256), 0, (hipStream_t)stream, x,
                      x_dtype, (const double*)sums, gamma, beta, eps, residual, act, y, y_dtype, y2, y2_dtype, HW, C,
                      total);

@@ -381,7 +381,8 @@ class PerformerSelfAttention(RFModule):
         m = self.fast_attention.projection_matrix.shape[0]
         pc = self.proj_scaled()
         gen = self.generalized
-        if RT.fused_favor and T() == torch.bfloat16 and dh == 64 and m == M_FEAT and Ls in (128, 256):
+        if RT.fused_favor and T() == torch.bfloat16 and dh == 64 and m == M_FEAT and (
+                Ls in (64, 128, 256) or (gen and Ls > 256 and Ls % 256 == 0)):
             # fused path: one projection GEMM (q|k|v) + one persistent kernel; q', k', ctx never leave the chip
             W3 = 3 * inner
             qkv = ops.linear(xn, self.wcat("qkv", [self.to_q, self.to_k, self.to_v]), None)

@@ -159,11 +159,12 @@ def test_softmax_and_tied():
     assert torch.equal(sym, sym.transpose(1, 2))  # reference tests/test_module.py:406-413
 
 
-def test_instnorm():
-    B, Hh, Cc = 2, 21, 24
-    x = randn(B, Hh, Hh, Cc) * 2 + 0.5
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+def test_instnorm(xdt):
+    B, Hh, Cc = 2, 37, 72
+    x = (randn(B, Hh, Hh, Cc) * 2 + 0.5).to(xdt).float()
     g, b, r = randn(Cc, seed=1), randn(Cc, seed=2), randn(B, Hh, Hh, Cc, seed=3)
     ref = torch.nn.functional.instance_norm(x.permute(0, 3, 1, 2), weight=g, bias=b, eps=1e-6).permute(0, 2, 3, 1)
-    y, y2 = ops.instnorm(x, g, b, residual=r, act=L.ACT_ELU, out_dtype=torch.float32, out2_dtype=torch.bfloat16)
+    y, y2 = ops.instnorm(x.to(xdt), g, b, residual=r, act=L.ACT_ELU, out_dtype=torch.float32, out2_dtype=torch.bfloat16)
     assert rel_err(y, torch.nn.functional.elu(ref + r)) < 1e-5
     assert rel_err(y2, y) < 1e-2

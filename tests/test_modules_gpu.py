@@ -111,8 +111,8 @@ def test_performer_self_attention(mode, generalized):
     assert rel(m(x.to(DEV)), O.performer_self_attention(state(m), "m", x, 8, generalized)) < mode[1]
 
 
-@pytest.mark.parametrize("generalized", [False, True])
-@pytest.mark.parametrize("n", [128, 256])
+@pytest.mark.parametrize("generalized,n", [(False, 64), (True, 64), (False, 128), (True, 128), (False, 256), (True, 256),
+                                           (True, 512), (True, 1024)])
 def test_fused_favor_attention(generalized, n):
     """fused FAVOR+ kernel (seq 128/256, bf16) vs the CPU oracle and vs the unfused kernel chain."""
     R.set_compute_dtype(torch.bfloat16)
@@ -278,3 +278,19 @@ def test_full_model_smooth_path_bf16_tolerance(mode):
     for k_ in ("theta", "phi", "dist", "omega"):
         assert errs[k_][1] < tol, (k_, errs[k_])
     assert agree == 1.0 if mode[0] == torch.float32 else agree > 0.9
+
+
+def test_long_sequence_smoke():
+    """BASELINE.json configs[3] in miniature (B=1, N=64, L=512 > 256): the chunked fused FAVOR path, the LS=64 MSA-column
+    path, the dense O(L^2) pair stages and the kNN/SE(3) buffers at their long-sequence sizes.  Shape + finiteness."""
+    R.set_compute_dtype(torch.bfloat16)
+    cfg = dict(CFG, n_three_track_blocks=2, max_len=600, n_neighbors=[64, 64])
+    m = build(lambda: R.RoseTTAFold(**cfg))
+    g = torch.Generator().manual_seed(0)
+    Ll, Nn = 512, 64
+    msa = torch.randint(0, 21, (1, Nn, Ll), generator=g)
+    aa = torch.arange(Ll)[None]
+    logits, xyz, plddt = m(msa.to(DEV), msa[:, 0].to(DEV), aa.to(DEV))
+    assert logits["dist"].shape == (1, Ll, Ll, 37) and xyz.shape == (1, Ll, 3, 3) and plddt.shape == (1, Ll)
+    for t in list(logits.values()) + [xyz, plddt]:
+        assert torch.isfinite(t).all()
