@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,7 +174,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -213,7 +215,7 @@ def main():
         log(f"{args.steps} timed steps: {dt:.3f}s")
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
 

@@ -303,31 +303,55 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const GemmP p
 #pragma unroll
       for (int i0 = 0; i0 < WM; i0 += IP) {
         __syncthreads();  // operand tiles (first pass) / previous pass fully consumed
+        // staged row index lr = (ii*WGM + wm)*16 + fr: decodes with shifts only on the read side.
+        // Common epilogues (no activation / ReLU, no row bias) take the branch-free form max(fma(acc, alpha, bias), lo).
+        const bool simple = (d.act == RF_ACT_NONE || d.act == RF_ACT_RELU) && d.bias_mode != RF_BIAS_ROW;
+        const float lo = d.act == RF_ACT_RELU ? 0.f : -INFINITY;
+        const float alpha = d.alpha;
 #pragma unroll
         for (int ii = 0; ii < IP; ++ii) {
           const int i = i0 + ii;
           if (i < WM) {
             const int m = m0 + wm * TM + i * 16 + fr;
-            const float bias_m = (d.bias_mode == RF_BIAS_ROW && m < d.M) ? d.bias[m] : 0.f;
-            char* lrow = smem + ((wm * IP + ii) * 16 + fr) * PITCH;
+            char* lrow = smem + ((ii * WGM + wm) * 16 + fr) * PITCH;
+            if (simple) {
 #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-              const int nl = wn * TN + j * 16 + 4 * fq;
-              const int n = n0 + nl;
-              float v[4];
-              const float bc[4] = {bias_c[j].x, bias_c[j].y, bias_c[j].z, bias_c[j].w};
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const float x = acc[i][j][e] * d.alpha + bc[e] + bias_m;
-                v[e] = apply_act(x, d.act, d.act_eps, (d.act_nvalid < 0 ? m < -d.act_nvalid : n + e < d.act_nvalid));
+              for (int j = 0; j < WN; ++j) {
+                const int nl = wn * TN + j * 16 + 4 * fq;
+                const float v0 = fmaxf(fmaf(acc[i][j][0], alpha, bias_c[j].x), lo);
+                const float v1 = fmaxf(fmaf(acc[i][j][1], alpha, bias_c[j].y), lo);
+                const float v2 = fmaxf(fmaf(acc[i][j][2], alpha, bias_c[j].z), lo);
+                const float v3 = fmaxf(fmaf(acc[i][j][3], alpha, bias_c[j].w), lo);
+                if constexpr (ESZ == 4) {
+                  *(float4*)(lrow + nl * 4) = make_float4(v0, v1, v2, v3);
+                } else {
+                  uint2 o;
+                  o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                  o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                  *(uint2*)(lrow + nl * 2) = o;
+                }
               }
-              if constexpr (ESZ == 4) {
-                *(float4*)(lrow + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
-              } else {
-                uint2 o;
-                o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                *(uint2*)(lrow + nl * 2) = o;
+            } else {
+              const float bias_m = (d.bias_mode == RF_BIAS_ROW && m < d.M) ? d.bias[m] : 0.f;
+#pragma unroll
+              for (int j = 0; j < WN; ++j) {
+                const int nl = wn * TN + j * 16 + 4 * fq;
+                const int n = n0 + nl;
+                float v[4];
+                const float bc[4] = {bias_c[j].x, bias_c[j].y, bias_c[j].z, bias_c[j].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float x = acc[i][j][e] * alpha + bc[e] + bias_m;
+                  v[e] = apply_act(x, d.act, d.act_eps, (d.act_nvalid < 0 ? m < -d.act_nvalid : n + e < d.act_nvalid));
+                }
+                if constexpr (ESZ == 4) {
+                  *(float4*)(lrow + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                  uint2 o;
+                  o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                  o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                  *(uint2*)(lrow + nl * 2) = o;
+                }
               }
             }
           }
@@ -341,9 +365,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const GemmP p
             constexpr int ROWS_LN = WGM * IP * 16;
             const int nch = d.N >> 2;
             for (int lr = wave; lr < ROWS_LN; lr += NW) {
-              const int w = lr / (IP * 16), rem = lr % (IP * 16);
-              const int i = i0 + rem / 16;
-              const int m = m0 + w * TM + i * 16 + (rem & 15);
+              const int w = (lr >> 4) % WGM;
+              const int i = i0 + lr / (WGM * 16);
+              const int m = m0 + w * TM + i * 16 + (lr & 15);
               if (i >= WM || m >= d.M) continue;
               const int64_t c_row = c_z + (int64_t)m * d.c_ri;
               float4 v[2];
@@ -400,9 +424,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const GemmP p
         const bool plain_c = d.c_rc <= 0 && d.c_cc <= 0;
         int lr = tid / CPR, c = tid % CPR;
         for (; lr < ROWS; lr += DR) {
-          const int w = lr / (IP * 16), rem = lr % (IP * 16);
-          const int i = i0 + rem / 16;
-          const int m = m0 + w * TM + i * 16 + (rem & 15);
+          const int w = (lr >> 4) % WGM;
+          const int i = i0 + lr / (WGM * 16);
+          const int m = m0 + w * TM + i * 16 + (lr & 15);
           const int n = n0 + c * EPC;
           if (i < WM && m < d.M && n < d.N) {
             const int64_t c_off = plain_c ? c_z + (int64_t)m * d.c_ri + n

@@ -41,6 +41,8 @@ def gather_results(logits, xyz, plddt, dst=0):
         return [(logits, xyz, plddt)]
     B, L = plddt.shape
     flat = pack_results(logits, xyz, plddt)
+    if dist.get_backend() == "gloo" and flat.is_cuda:
+        flat = flat.cpu()  # gloo has no device gather; RCCL ("nccl") gathers in HBM
     world, rank = dist.get_world_size(), dist.get_rank()
     bufs = [torch.empty_like(flat) for _ in range(world)] if rank == dst else None
     dist.gather(flat, bufs, dst=dst)
