@@ -278,7 +278,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const GemmP p
     bias_c[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (d.bias_mode == RF_BIAS_COL) {
       if (n + 3 < d.N) {
-        bias_c[j] = make_float4(d.bias[n], d.bias[n + 1], d.bias[n + 2], d.bias[n + 3]);
+        if (p.vec_store)
+          bias_c[j] = *(const float4*)(d.bias + n);  // N % 4 == 0 and the bias vector is 16-byte aligned (checked on the host)
+        else
+          bias_c[j] = make_float4(d.bias[n], d.bias[n + 1], d.bias[n + 2], d.bias[n + 3]);
       } else {
         if (n < d.N) bias_c[j].x = d.bias[n];
         if (n + 1 < d.N) bias_c[j].y = d.bias[n + 1];
@@ -308,13 +311,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const GemmP p
         const bool simple = (d.act == RF_ACT_NONE || d.act == RF_ACT_RELU) && d.bias_mode != RF_BIAS_ROW;
         const float lo = d.act == RF_ACT_RELU ? 0.f : -INFINITY;
         const float alpha = d.alpha;
+        const bool raw = simple && d.act == RF_ACT_NONE && d.bias_mode == RF_BIAS_NONE && alpha == 1.0f;
 #pragma unroll
         for (int ii = 0; ii < IP; ++ii) {
           const int i = i0 + ii;
           if (i < WM) {
             const int m = m0 + wm * TM + i * 16 + fr;
             char* lrow = smem + ((ii * WGM + wm) * 16 + fr) * PITCH;
-            if (simple) {
+            if (raw) {  // alpha = 1, no bias, no activation (e.g. the q|k|v projections): convert and store
+#pragma unroll
+              for (int j = 0; j < WN; ++j) {
+                const int nl = wn * TN + j * 16 + 4 * fq;
+                if constexpr (ESZ == 4) {
+                  *(f32x4*)(lrow + nl * 4) = acc[i][j];
+                } else {
+                  uint2 o;
+                  o.x = (unsigned)f2bf(acc[i][j][0]) | ((unsigned)f2bf(acc[i][j][1]) << 16);
+                  o.y = (unsigned)f2bf(acc[i][j][2]) | ((unsigned)f2bf(acc[i][j][3]) << 16);
+                  *(uint2*)(lrow + nl * 2) = o;
+                }
+              }
+            } else if (simple) {
 #pragma unroll
               for (int j = 0; j < WN; ++j) {
                 const int nl = wn * TN + j * 16 + 4 * fq;
@@ -686,6 +703,7 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   const size_t esz = d.c_dtype == RF_F32 ? 4 : 2;
   if (((uintptr_t)d.C % (4 * esz)) != 0) p.vec_store = 0;
   if (d.residual && ((uintptr_t)d.residual % 16) != 0) p.vec_store = 0;
+  if (d.bias && ((uintptr_t)d.bias % 16) != 0) p.vec_store = 0;
   {
     // staged (LDS -> coalesced 16-byte rows) epilogue legal?
     const int epc = d.c_dtype == RF_F32 ? 4 : 8;
@@ -731,7 +749,9 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
     if (d.M >= 1024 && rows >= 16384 && t.bk == 64 && (d.N % 288 == 0 || d.N % 256 == 0 || d.N % 192 == 0 || d.N == 128)) {
       // long activation panels: 8-wave 256-row tiles halve the DMA bytes per FLOP
       t.bm = 256;
-      t.bn = d.N % 288 == 0 ? 288 : (d.N % 256 == 0 ? 256 : (d.N % 192 == 0 ? 192 : 128));
+      // measured on MI355X (tools/gemm_bench.py): 256-wide tiles win whenever they divide N (and for N = 1152),
+      // 288-wide for the d_pair-wide outputs, 192-wide for the d_msa-wide ones
+      t.bn = (d.N % 256 == 0 || d.N == 1152) ? 256 : (d.N % 288 == 0 ? 288 : (d.N % 192 == 0 ? 192 : 128));
     } else {
       t.bn = pick_bn(d.N);
       t.bm = d.M > 64 && ((d.M + 127) / 128) * 128 <= ((d.M + 63) / 64) * 64 + 32 ? 128 : 64;
