@@ -168,13 +168,13 @@ int rf_favor_softmax_features(const void* dash, const void* x, const int64_t xs[
  * o, head h) item the sequence s in [0,seq_len) is attended with
  *     q' = phi(q Pc^T), k' = phi(k Pc^T), out = (q' (k'^T v)) / (q' . sum_s k')
  * entirely on-chip.  qkv: bf16 rows holding q|k|v at column offsets q_off/k_off/v_off (+ h*dim_head); the row of
- * (b,o,s) starts at b*x_strides[0] + o*x_strides[1] + s*x_strides[2] (elements); out (bf16) likewise with o_strides,
- * head h at column h*dim_head.  pc: bf16 [288][64] projection matrix pre-scaled by dim_head^-1/4, rows >= 266 zero.
+ * (b,o,s) of head h starts at b*x_strides[0] + o*x_strides[1] + s*x_strides[2] + h*x_strides[3] (elements); out
+ * (bf16) likewise with o_strides, head h at column h*dim_head.  pc: bf16 [288][64] projection matrix pre-scaled by dim_head^-1/4, rows >= 266 zero.
  * Supported: dim_head 64, n_features 266, seq_len 64/128/256, and (ReLU kernel) any multiple of 256 walked in 256-row
  * chunks -- the L=1024 configuration (other shapes: use the unfused chain of rf_gemm +
  * rf_favor_softmax_features + rf_linattn_normalize).  softmax_kernel != 0: exp features with the library's
  * stabilisers (per-row max for q, per-(b,o,h) max for k) and eps; else relu(x)+eps. */
-int rf_favor_attention(const void* qkv, const void* pc, void* out, const int64_t x_strides[3],
+int rf_favor_attention(const void* qkv, const void* pc, void* out, const int64_t x_strides[4],
                        const int64_t o_strides[3], int q_off, int k_off, int v_off, int n_b, int n_o, int n_h,
                        int seq_len, int dim_head, int n_features, int softmax_kernel, float eps, void* stream);
 

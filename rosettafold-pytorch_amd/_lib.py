@@ -53,7 +53,7 @@ PROTOTYPES = {
     "rf_copy4d": [vp, i32, C.POINTER(I64x4), vp, i32, C.POINTER(I64x4), C.POINTER(I64x4), vp],
     "rf_axpby": [vp, i32, f32, vp, i32, f32, vp, i32, i64, vp],
     "rf_favor_softmax_features": [vp, vp, C.POINTER(I64x4), i32, i32, vp, i32, i64, i32, i32, i32, i32, i32, i32, f32, vp],
-    "rf_favor_attention": [vp, vp, vp, C.POINTER(I64x3), C.POINTER(I64x3), i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
+    "rf_favor_attention": [vp, vp, vp, C.POINTER(I64x4), C.POINTER(I64x3), i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "rf_linattn_normalize": [vp, i64, vp, i32, i64, i64, i32, vp],
     "rf_tile_1d_feats": [vp, vp, i32, i64, i32, i32, i32, i32, vp],
     "rf_graph_attention": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, f32, vp],

@@ -35,10 +35,12 @@ struct FavorAttnP {
   const bf16_t* pc;   // [288][64] projection pre-scaled by d^-1/4, zero rows beyond 266
   bf16_t* out;        // [.., inner]
   int64_t x_b, x_o, x_s;  // element strides of qkv for batch / outer index / sequence index
+  int64_t x_h;            // element stride of qkv between heads (64 for rows holding all heads, Ls*64 for head-major tiles)
   int64_t o_b, o_o, o_s;  // same for out
   int q_off, k_off, v_off;
   int n_o, n_h, nitems;
   int nchunks;  // sequence = nchunks * LS rows (ReLU kernel only; softmax kernel: 1)
+  int dbg;      // timing experiments only: 1 = skip the phase-A MFMA loop, 2 = skip the phase-B loop
   float eps;
 };
 
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
     const int h = item % p.n_h;
     const int t = item / p.n_h;
     const int o = t % p.n_o, b = t / p.n_o;
-    xb = (int64_t)b * p.x_b + (int64_t)o * p.x_o + h * FV_DH;
+    xb = (int64_t)b * p.x_b + (int64_t)o * p.x_o + (int64_t)h * p.x_h;
     ob = (int64_t)b * p.o_b + (int64_t)o * p.o_o + h * FV_DH;
   };
 
@@ -116,10 +118,17 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
     fv_load_tile(smem, K_OFF, p.qkv + xb + p.k_off, p.x_s, LS, wave, lane);
     fv_load_tile(smem, V_OFF, p.qkv + xb + p.v_off, p.x_s, LS, wave, lane);
   }
+  bool first = true;
   for (; item < p.nitems; item += gridDim.x) {
     int64_t xb, ob;
     item_base(item, xb, ob);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // wait for the K/V DMAs but NOT for the previous item's output stores (the ST*4 youngest operations of this wave):
+    // a counted vmcnt lets them drain behind this item's phase A
+    if (first)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST * 4) : "memory");
+    first = false;
     __syncthreads();  // K, V (and Pc on the first item) have landed; previous item fully consumed
     // Q fragments of this wave's rows straight from global; consumed in phase B, so phase A hides the latency
     bf16x8 qf[ST][2];
@@ -426,19 +435,410 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 8-wave variant (2 waves per SIMD: a lone wave issues one VALU op per 4 cycles, two co-resident waves one per 2, and
+// the feature maps are VALU-bound).  Phase A: wave = (feature group g = 5,4,4,4 tiles) x (sequence half hs); the two
+// halves' partial contexts are combined through the ctx^T image (half 1 publishes bf16, half 0 adds its fp32 partial
+// and republishes).  Phase B: the sequence is split over all eight waves.  Same maths, operands and LDS image as above.
+// ------------------------------------------------------------------------------------------------------------------
+template <int LS, bool SOFTMAX>
+__global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAttnP p) {
+  constexpr int NSB = LS / 32;                    // s-blocks (pairs of s-tiles) per chunk
+  constexpr int NSBH = NSB / 2;                   // per sequence half
+  constexpr int STB = LS >= 128 ? LS / 128 : 1;   // s-tiles per wave in phase B
+  constexpr int NWB = LS / (16 * STB);            // waves active in phase B (8, or 4 for LS = 64)
+  constexpr int PC_OFF = 0;
+  constexpr int K_OFF = FV_MPAD * 128;
+  constexpr int V_OFF = K_OFF + LS * 128;
+  constexpr int CTX_OFF = V_OFF + LS * 128;
+  constexpr int DIAG_OFF = CTX_OFF + FV_DROWS * FV_CTX_LD;
+  constexpr int RED_OFF = DIAG_OFF + LS * 4;
+  static_assert(NSB % 2 == 0, "sequence halves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
+  const int g = wave & 3, hs = wave >> 2;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nm = g == 0 ? 5 : 4;
+  const int m0t = g == 0 ? 0 : 5 + 4 * (g - 1);
+  const f32x4 epsv = {p.eps, p.eps, p.eps, p.eps};
+  Frag ones;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) ones.u[k] = fr == 0 ? 0x3F803F80u : 0u;
+
+  auto load_tile8 = [&](int lds_off, const bf16_t* gp, int64_t stride, int nrows) {
+    const int ninstr = nrows * 8 / 64;
+    for (int it = wave; it < ninstr; it += 8) {
+      const int slot = it * 64 + lane;
+      const int row = slot >> 3;
+      const int clog = (slot & 7) ^ (row & 7);
+      fv_glds(gp + (int64_t)row * stride + clog * 8, smem + lds_off + it * 1024);
+    }
+  };
+  load_tile8(PC_OFF, p.pc, FV_DH, FV_MPAD);
+  for (int i = tid; i < FV_DROWS * FV_CTX_LD / 4; i += 512) ((unsigned*)(smem + CTX_OFF))[i] = 0u;
+
+  auto item_base = [&](int item, int64_t& xb, int64_t& ob) {
+    const int h = item % p.n_h;
+    const int t = item / p.n_h;
+    const int o = t % p.n_o, b = t / p.n_o;
+    xb = (int64_t)b * p.x_b + (int64_t)o * p.x_o + (int64_t)h * p.x_h;
+    ob = (int64_t)b * p.o_b + (int64_t)o * p.o_o + h * FV_DH;
+  };
+  const int nch = p.nchunks;
+  int item = blockIdx.x;
+  if (item < p.nitems) {
+    int64_t xb, ob;
+    item_base(item, xb, ob);
+    load_tile8(K_OFF, p.qkv + xb + p.k_off, p.x_s, LS);
+    load_tile8(V_OFF, p.qkv + xb + p.v_off, p.x_s, LS);
+  }
+  bool first = true;
+  for (; item < p.nitems; item += gridDim.x) {
+    int64_t xb, ob;
+    item_base(item, xb, ob);
+    if (first || wave >= NWB)  // (waves idle in phase B issued no stores: their youngest operations are the DMAs)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STB * 4) : "memory");
+    first = false;
+    __syncthreads();
+    bf16x8 qf[STB][2];
+    auto load_q = [&](int chunk) {
+      if (wave < NWB) {
+#pragma unroll
+        for (int t = 0; t < STB; ++t) {
+          const int s = chunk * LS + (wave * STB + t) * 16 + fr;
+          const bf16_t* qrow = p.qkv + xb + p.q_off + (int64_t)s * p.x_s;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) qf[t][kk] = *(const bf16x8*)(qrow + (kk * 4 + fq) * 8);
+        }
+      }
+    };
+    load_q(0);
+
+    float gmax = 0.f;
+    if constexpr (SOFTMAX) {
+      for (int s = tid; s < LS; s += 512) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const bf16x8 x = *(const bf16x8*)(smem + K_OFF + s * 128 + c * 16);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = bf2f((bf16_t)x[e]);
+            a = fmaf(f, f, a);
+          }
+        }
+        ((float*)(smem + DIAG_OFF))[s] = a * (0.0625f * 1.4426950408889634f);
+      }
+      // pass 0: global max of the key logits (this wave: its feature tiles x its sequence half)
+      float mx = -INFINITY;
+      for (int u = hs * NSBH; u < (hs + 1) * NSBH; ++u) {
+        bf16x8 kf[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+            kf[t][kk] = *(const bf16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + fr, kk * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          if (j < nm) {
+            bf16x8 pfj[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) pfj[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off((m0t + j) * 16 + fr, kk * 4 + fq));
+            const bool valid = (m0t + j) * 16 + fr < FV_M;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              f32x4 a = {0.f, 0.f, 0.f, 0.f};
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], pfj[0], a, 0, 0, 0);
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], pfj[1], a, 0, 0, 0);
+              if (valid) mx = fmaxf(mx, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
+            }
+          }
+        }
+      }
+      mx = wave_max(mx);
+      if (lane == 0) ((float*)(smem + RED_OFF))[wave] = mx;
+      __syncthreads();
+      const float* red = (const float*)(smem + RED_OFF);
+      gmax = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
+    }
+
+    // ---------------- phase A ----------------
+    f32x4 ctx[5][FV_DT];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int i = 0; i < FV_DT; ++i) ctx[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ck = 0; ck < nch; ++ck) {
+      if (ck > 0) {
+        __syncthreads();
+        load_tile8(K_OFF, p.qkv + xb + p.k_off + (int64_t)ck * LS * p.x_s, p.x_s, LS);
+        load_tile8(V_OFF, p.qkv + xb + p.v_off + (int64_t)ck * LS * p.x_s, p.x_s, LS);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+      for (int u = hs * NSBH; u < ((p.dbg & 1) ? hs * NSBH : (hs + 1) * NSBH); ++u) {
+        bf16x8 kf[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk)
+            kf[t][kk] = *(const bf16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + fr, kk * 4 + fq));
+        Frag vf[4];
+        {
+          const int p4 = fr & 3;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              const int row = u * 32 + half * 16 + 4 * fq + (fr >> 2);
+              const int off = V_OFF + swz_off(row, i * 2 + (p4 >> 1)) + (p4 & 1) * 8;
+              const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off));
+              vf[i].h[half] = __builtin_bit_cast(uint2, r);
+            }
+          }
+        }
+        f32x4 init[2] = {epsv, epsv};
+        if constexpr (SOFTMAX) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const float4 d4 = *(const float4*)(smem + DIAG_OFF + ((2 * u + t) * 16 + 4 * fq) * 4);
+            init[t] = (f32x4){-(d4.x + gmax), -(d4.y + gmax), -(d4.z + gmax), -(d4.w + gmax)};
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          if (j < nm) {
+            bf16x8 pfj[2];  // re-read per s-block: 8 registers instead of 40 resident ones
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) pfj[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off((m0t + j) * 16 + fr, kk * 4 + fq));
+            f32x4 a[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              a[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], pfj[0], init[t], 0, 0, 0);
+              a[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], pfj[1], a[t], 0, 0, 0);
+            }
+            float f[2][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                if constexpr (SOFTMAX)
+                  f[t][r] = __builtin_amdgcn_exp2f(a[t][r]) + p.eps;
+                else
+                  f[t][r] = fmaxf(a[t][r], p.eps);
+              }
+            if ((m0t + j) == FV_MT - 1 && fr >= FV_M - 16 * (FV_MT - 1)) {
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[t][r] = 0.f;
+            }
+            Frag kfr;
+            kfr.u[0] = pack2(f[0][0], f[0][1]);
+            kfr.u[1] = pack2(f[0][2], f[0][3]);
+            kfr.u[2] = pack2(f[1][0], f[1][1]);
+            kfr.u[3] = pack2(f[1][2], f[1][3]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              ctx[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr.v, vf[i].v, ctx[j][i], 0, 0, 0);
+            ctx[j][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr.v, ones.v, ctx[j][4], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // combine the two sequence halves through the ctx^T image: half 1 publishes, half 0 adds and republishes
+    if (hs == 1) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        if (j < nm) {
+#pragma unroll
+          for (int i = 0; i < FV_DT; ++i) {
+            uint2 w;
+            w.x = pack2(ctx[j][i][0], ctx[j][i][1]);
+            w.y = pack2(ctx[j][i][2], ctx[j][i][3]);
+            *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ((m0t + j) * 16 + 4 * fq) * 2) = w;
+          }
+        }
+    }
+    __syncthreads();
+    if (hs == 0) {
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        if (j < nm) {
+#pragma unroll
+          for (int i = 0; i < FV_DT; ++i) {
+            uint2* ptr = (uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ((m0t + j) * 16 + 4 * fq) * 2);
+            const uint2 o = *ptr;
+            uint2 w;
+            w.x = pack2(ctx[j][i][0] + bf2f((bf16_t)(o.x & 0xffff)), ctx[j][i][1] + bf2f((bf16_t)(o.x >> 16)));
+            w.y = pack2(ctx[j][i][2] + bf2f((bf16_t)(o.y & 0xffff)), ctx[j][i][3] + bf2f((bf16_t)(o.y >> 16)));
+            *ptr = w;
+          }
+        }
+    }
+    __syncthreads();  // ctx^T complete; K and V tiles are free again
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+      const int nxt = item + gridDim.x;
+      if (nxt < p.nitems) {
+        int64_t xb2, ob2;
+        item_base(nxt, xb2, ob2);
+        load_tile8(K_OFF, p.qkv + xb2 + p.k_off, p.x_s, LS);
+        load_tile8(V_OFF, p.qkv + xb2 + p.v_off, p.x_s, LS);
+      }
+    }
+
+    // ---------------- phase B ----------------
+    for (int qc = 0; qc < nch; ++qc) {
+      if (qc > 0) load_q(qc);
+      if (wave < NWB) {
+        f32x4 qinit[STB];
+#pragma unroll
+        for (int t = 0; t < STB; ++t) qinit[t] = epsv;
+        if constexpr (SOFTMAX) {
+          float dq[STB], rmax[STB];
+#pragma unroll
+          for (int t = 0; t < STB; ++t) {
+            float a = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float f = bf2f((bf16_t)qf[t][kk][e]);
+                a = fmaf(f, f, a);
+              }
+            a += __shfl_xor(a, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            dq[t] = a * (0.0625f * 1.4426950408889634f);
+            rmax[t] = -INFINITY;
+          }
+          for (int j = 0; j < FV_MT; ++j) {
+            bf16x8 pfr[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) pfr[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off(j * 16 + fr, kk * 4 + fq));
+#pragma unroll
+            for (int t = 0; t < STB; ++t) {
+              f32x4 a = {0.f, 0.f, 0.f, 0.f};
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[0], qf[t][0], a, 0, 0, 0);
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[1], qf[t][1], a, 0, 0, 0);
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (j * 16 + 4 * fq + r < FV_M) rmax[t] = fmaxf(rmax[t], a[r]);
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < STB; ++t) {
+            rmax[t] = fmaxf(rmax[t], __shfl_xor(rmax[t], 16, 64));
+            rmax[t] = fmaxf(rmax[t], __shfl_xor(rmax[t], 32, 64));
+            const float off = -(dq[t] + rmax[t]);
+            qinit[t] = (f32x4){off, off, off, off};
+          }
+        }
+        f32x4 num[FV_DT][STB];
+#pragma unroll
+        for (int t = 0; t < STB; ++t)
+#pragma unroll
+          for (int i = 0; i < FV_DT; ++i) num[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto mblock = [&](int u, auto last_tag) {
+          constexpr bool LAST = decltype(last_tag)::value;
+          float f[2][STB][4];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            if (LAST && jj == 1) {
+#pragma unroll
+              for (int t = 0; t < STB; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) f[jj][t][r] = 0.f;
+            } else {
+              const int j = 2 * u + jj;
+              bf16x8 pfr[2];
+#pragma unroll
+              for (int kk = 0; kk < 2; ++kk) pfr[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off(j * 16 + fr, kk * 4 + fq));
+#pragma unroll
+              for (int t = 0; t < STB; ++t) {
+                f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[0], qf[t][0], qinit[t], 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[1], qf[t][1], a, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  float x;
+                  if constexpr (SOFTMAX)
+                    x = __builtin_amdgcn_exp2f(a[r]) + p.eps;
+                  else
+                    x = fmaxf(a[r], p.eps);
+                  if (LAST && 4 * fq + r >= FV_M - 16 * (FV_MT - 1)) x = 0.f;
+                  f[jj][t][r] = x;
+                }
+              }
+            }
+          }
+          Frag cf[FV_DT];
+#pragma unroll
+          for (int i = 0; i < FV_DT; ++i) {
+            const char* base = smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + (32 * u + 4 * fq) * 2;
+            cf[i].h[0] = *(const uint2*)base;
+            cf[i].h[1] = *(const uint2*)(base + 32);
+          }
+#pragma unroll
+          for (int t = 0; t < STB; ++t) {
+            Frag qfr;
+            qfr.u[0] = pack2(f[0][t][0], f[0][t][1]);
+            qfr.u[1] = pack2(f[0][t][2], f[0][t][3]);
+            qfr.u[2] = pack2(f[1][t][0], f[1][t][1]);
+            qfr.u[3] = pack2(f[1][t][2], f[1][t][3]);
+#pragma unroll
+            for (int i = 0; i < FV_DT; ++i)
+              num[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[i].v, qfr.v, num[i][t], 0, 0, 0);
+          }
+        };
+        for (int u = 0; u < ((p.dbg & 2) ? 0 : (FV_MT - 1) / 2); ++u) mblock(u, std::false_type{});
+        mblock((FV_MT - 1) / 2, std::true_type{});
+#pragma unroll
+        for (int t = 0; t < STB; ++t) {
+          const float dn = __shfl(num[4][t][0], fr, 64);
+          const float inv = 1.f / dn;
+          const int s = qc * LS + (wave * STB + t) * 16 + fr;
+          bf16_t* orow = p.out + ob + (int64_t)s * p.o_s;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            uint2 w;
+            w.x = pack2(num[i][t][0] * inv, num[i][t][1] * inv);
+            w.y = pack2(num[i][t][2] * inv, num[i][t][3] * inv);
+            *(uint2*)(orow + i * 16 + 4 * fq) = w;
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int LS, bool SM>
 static int launch_favor(const FavorAttnP& p, hipStream_t s) {
   const size_t lds = (size_t)FV_MPAD * 128 + 2 * (size_t)LS * 128 + (size_t)FV_DROWS * FV_CTX_LD + LS * 4 + 64;
-  auto k = favor_attention_kernel<LS, SM>;
-  static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-  (void)once;
   int ncu = 256;
   const int grid = p.nitems < ncu ? p.nitems : ncu;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
+  // measured (tools/favor_bench.py): the 8-wave kernel wins for the ReLU features (no AGPR traffic at <= 256
+  // registers); the softmax-feature variant spills there, so it stays on the 4-wave kernel.  RF_FAVOR4 / RF_FAVOR8 force one.
+  static const bool force4 = getenv("RF_FAVOR4") != nullptr, force8 = getenv("RF_FAVOR8") != nullptr;
+  const bool use4 = force4 || (SM && !force8);
+  if (use4) {
+    auto k = favor_attention_kernel<LS, SM>;
+    static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
+  } else {
+    auto k = favor_attention_kernel8<LS, SM>;
+    static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, p);
+  }
   return rf_launch_status();
 }
 
-extern "C" int rf_favor_attention(const void* qkv, const void* pc, void* out, const int64_t x_strides[3],
+extern "C" int rf_favor_attention(const void* qkv, const void* pc, void* out, const int64_t x_strides[4],
                                   const int64_t o_strides[3], int q_off, int k_off, int v_off, int n_b, int n_o,
                                   int n_h, int seq_len, int dim_head, int n_features, int softmax_kernel, float eps,
                                   void* stream) {
@@ -453,18 +853,20 @@ extern "C" int rf_favor_attention(const void* qkv, const void* pc, void* out, co
   if (((uintptr_t)qkv % 16) || ((uintptr_t)pc % 16) || ((uintptr_t)out % 8)) return RF_EALIGN;
   for (int i = 0; i < 3; ++i)
     if (x_strides[i] % 8 || o_strides[i] % 4) return RF_EALIGN;
+  if (x_strides[3] % 8) return RF_EALIGN;
   if (q_off % 8 || k_off % 8 || v_off % 8) return RF_EALIGN;
   FavorAttnP p;
   p.qkv = (const bf16_t*)qkv;
   p.pc = (const bf16_t*)pc;
   p.out = (bf16_t*)out;
-  p.x_b = x_strides[0]; p.x_o = x_strides[1]; p.x_s = x_strides[2];
+  p.x_b = x_strides[0]; p.x_o = x_strides[1]; p.x_s = x_strides[2]; p.x_h = x_strides[3];
   p.o_b = o_strides[0]; p.o_o = o_strides[1]; p.o_s = o_strides[2];
   p.q_off = q_off; p.k_off = k_off; p.v_off = v_off;
   p.n_o = n_o; p.n_h = n_h;
   p.nitems = n_b * n_o * n_h;
   p.eps = eps;
   p.nchunks = nchunks;
+  p.dbg = getenv("RF_FAVOR_DBG") ? atoi(getenv("RF_FAVOR_DBG")) : 0;
   hipStream_t s = (hipStream_t)stream;
   if (ls == 256) return softmax_kernel ? launch_favor<256, true>(p, s) : launch_favor<256, false>(p, s);
   if (ls == 128) return softmax_kernel ? launch_favor<128, true>(p, s) : launch_favor<128, false>(p, s);

@@ -28,6 +28,7 @@ struct GemmP {
   int dbg;        // timing experiments: 1 = skip epilogue stores, 2 = skip the K loop
   int stage_epi;  // 1: C tile goes through LDS and is written as whole rows (16-byte coalesced stores)
   int nt_store;   // 1: streaming (nontemporal) stores for large outputs
+  int c_pow2, c_rsh, c_csh;  // C split factors are powers of two: shift amounts
 };
 
 __device__ __forceinline__ int64_t split_off(int idx, int rc, int64_t ro, int64_t ri) {
@@ -446,8 +447,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void gemm_bf16_kernel(const GemmP p
           const int m = m0 + w * TM + i * 16 + (lr & 15);
           const int n = n0 + c * EPC;
           if (i < WM && m < d.M && n < d.N) {
-            const int64_t c_off = plain_c ? c_z + (int64_t)m * d.c_ri + n
-                                          : c_z + split_off(m, d.c_rc, d.c_ro, d.c_ri) + split_off(n, d.c_cc, d.c_co, 1);
+            int64_t c_off;
+            if (plain_c) {
+              c_off = c_z + (int64_t)m * d.c_ri + n;
+            } else if (p.c_pow2) {  // both split factors are powers of two: shifts instead of divisions
+              const int64_t ro = d.c_rc > 0 ? (int64_t)(m >> p.c_rsh) * d.c_ro + (int64_t)(m & (d.c_rc - 1)) * d.c_ri
+                                            : (int64_t)m * d.c_ri;
+              const int64_t co = d.c_cc > 0 ? (int64_t)(n >> p.c_csh) * d.c_co + (n & (d.c_cc - 1)) : n;
+              c_off = c_z + ro + co;
+            } else {
+              c_off = c_z + split_off(m, d.c_rc, d.c_ro, d.c_ri) + split_off(n, d.c_cc, d.c_co, 1);
+            }
             const char* src = smem + lr * PITCH + c * 16;
             if constexpr (ESZ == 4) {
               float4 v = *(const float4*)src;
@@ -712,6 +722,12 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
                   ok(d.c_bs[0]) && ok(d.c_bs[1]) && ok(d.c_bs[2]) && ((uintptr_t)d.C % 16) == 0 &&
                   (!d.residual || (d.c_dtype == RF_F32 && ((uintptr_t)d.residual % 16) == 0));
     if (getenv("RF_NO_STAGED_EPILOGUE")) p.stage_epi = 0;
+  }
+  {
+    auto p2 = [](int v) { return v <= 0 || (v & (v - 1)) == 0; };
+    p.c_pow2 = p2(d.c_rc) && p2(d.c_cc);
+    p.c_rsh = d.c_rc > 0 ? __builtin_ctz(d.c_rc) : 0;
+    p.c_csh = d.c_cc > 0 ? __builtin_ctz(d.c_cc) : 0;
   }
   hipStream_t s = (hipStream_t)stream;
   const bool want_ln = d.ln_out != nullptr;

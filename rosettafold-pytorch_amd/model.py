@@ -34,6 +34,7 @@ VT_ROWS = 80   # 64 value rows + the ones row (k' sums) padded to a multiple of 
 class _Runtime:
     dtype = torch.bfloat16
     fused_favor = True  # use the fused FAVOR+ kernel when the shape allows (bf16, dim_head 64, seq 128/256)
+    head_major_qkv = bool(int(__import__("os").environ.get("RF_HEAD_MAJOR_QKV", "0")))
 
 
 RT = _Runtime()
@@ -385,11 +386,24 @@ class PerformerSelfAttention(RFModule):
                 Ls in (64, 128, 256) or (gen and Ls > 256 and Ls % 256 == 0)):
             # fused path: one projection GEMM (q|k|v) + one persistent kernel; q', k', ctx never leave the chip
             W3 = 3 * inner
-            qkv = ops.linear(xn, self.wcat("qkv", [self.to_q, self.to_k, self.to_v]), None)
             o = torch.empty(R, inner, device=dev, dtype=T())
             pcf = pc if gen else self.proj_scaled(log2e=True)
-            ops.favor_attention(qkv, pcf, o, (RB * W3, so * W3, ss * W3), (RB * inner, so * inner, ss * inner),
-                                0, inner, 2 * inner, B, Lo, H, Ls, dh, m, not gen, 1e-3 if gen else 1e-4)
+            eps = 1e-3 if gen else 1e-4
+            wqkv = self.wcat("qkv", [self.to_q, self.to_k, self.to_v])
+            if RT.head_major_qkv:
+                # q|k|v written head-major [B, Lo, 3, H, Ls, 64] straight from the projection GEMM's epilogue: every
+                # (b, o, head) tile the FAVOR kernel DMAs is then one contiguous 8 KB x (Ls/64) block
+                qkv = torch.empty(B, Lo, 3, H, Ls, dh, device=dev, dtype=T())
+                so_c, ss_c = 3 * H * Ls * dh, dh
+                c_ro, c_ri = (ss_c, so_c) if axis == 1 else (so_c, ss_c)  # row m = p1*L2 + p2
+                ops.gemm(xn, wqkv, qkv, RB, W3, D, batch=(B, 1, 1), a_bs=(RB * D, 0, 0),
+                         c_bs=(Lo * so_c, 0, 0), c_row=(L2, c_ro, c_ri), c_col=(dh, Ls * dh))
+                ops.favor_attention(qkv, pcf, o, (Lo * so_c, so_c, dh, Ls * dh), (RB * inner, so * inner, ss * inner),
+                                    0, H * Ls * dh, 2 * H * Ls * dh, B, Lo, H, Ls, dh, m, not gen, eps)
+            else:
+                qkv = ops.linear(xn, wqkv, None)
+                ops.favor_attention(qkv, pcf, o, (RB * W3, so * W3, ss * W3, dh), (RB * inner, so * inner, ss * inner),
+                                    0, inner, 2 * inner, B, Lo, H, Ls, dh, m, not gen, eps)
             return ops.linear_residual_ln(o, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln)
         qk = ops.linear(xn, self.wcat("qk", [self.to_q, self.to_k]), None)  # [R, 2*inner]
         # q' [B,Lo,H,Ls,M_PAD]

@@ -334,7 +334,7 @@ def favor_attention(qkv, pc, out, x_strides, o_strides, q_off, k_off, v_off, n_b
     _need_cuda(qkv, pc, out)
     if qkv.dtype != BF16 or pc.dtype != BF16 or out.dtype != BF16:
         raise TypeError("favor_attention is the bf16 MFMA path")
-    xs = L.I64x3(*[int(v) for v in x_strides])
+    xs = L.I64x4(*[int(v) for v in x_strides])
     os_ = L.I64x3(*[int(v) for v in o_strides])
     check(lib.rf_favor_attention(ptr(qkv), ptr(pc), ptr(out), C.byref(xs), C.byref(os_), q_off, k_off, v_off, n_b, n_o,
                                  n_h, seq_len, dim_head, n_features, 1 if softmax_kernel else 0, eps, stream()),

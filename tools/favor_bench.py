@@ -19,7 +19,7 @@ for name, gen, B, L1, L2, D, H, axis in [("pair row", True, 4, 256, 256, 288, 8,
     ss, so = (L2, 1) if axis == 1 else (1, L2)
     RB, W3 = L1 * L2, 3 * inner
     pc = m.proj_scaled(log2e=not gen)
-    f = lambda: ops.favor_attention(qkv, pc, o, (RB * W3, so * W3, ss * W3), (RB * inner, so * inner, ss * inner), 0, inner, 2 * inner, B, Lo, H, Ls, 64, 266, not gen, 1e-3 if gen else 1e-4)
+    f = lambda: ops.favor_attention(qkv, pc, o, (RB * W3, so * W3, ss * W3, 64), (RB * inner, so * inner, ss * inner), 0, inner, 2 * inner, B, Lo, H, Ls, 64, 266, not gen, 1e-3 if gen else 1e-4)
     t = timeit(f)
     fl = B * Lo * H * (4 * 2 * Ls * 64 * 266)
     print(f"{name}: {t*1e3:.0f} us, {fl/t/1e9:.0f} TF/s (algorithmic, 266 features)", flush=True)
