@@ -46,3 +46,6 @@ static inline int rf_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
+
+// gemm_fast.hip: persistent plain-layout bf16 GEMM; returns 1 (launched, *rc = status) or 0 (descriptor does not fit)
+int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream);

@@ -1,0 +1,303 @@
+// Persistent plain-layout bf16 GEMM for the long activation panels of the forward path (gfx950 / MI355X).
+//
+// rf_gemm routes here when the operands are plain row-major (activations [M, K], nn.Linear weight [N, K],
+// output [M, N]; rf.py:195-281), M is a multiple of 256 and N a multiple of the tile width: the q|k|v / feed-forward /
+// output projections of the MSA and pair tracks, i.e. >90 % of the GEMM time of the bench configuration.
+//
+// What differs from the generic kernel in gemm.hip (same MFMA tile, same LDS image and swizzle):
+//   * persistent workgroups: one 512-thread workgroup per CU walks tiles lid = round * grid + slot.  The K steps of
+//     consecutive tiles form ONE double-buffered DMA pipeline: the last K step of a tile prefetches the first K step
+//     of the next tile, so the launch gap, the address set-up and the first-tile DMA latency (2-4 us of a 16 us
+//     tile, measured with tools/gemm_stamps.py) are paid once per workgroup instead of once per tile, and a tile's
+//     stores drain under the next tile's K loop.
+//   * all global addresses are "uniform base + 32-bit lane offset": no per-slot 64-bit pointers live in VGPRs.
+//   * the bias is folded into the accumulator init; the epilogue is max(acc, lo) -> wave-private LDS strips ->
+//     16-byte row-contiguous stores (see gemm.hip), specialised at compile time on the output type / residual.
+#include <type_traits>
+
+#include "common.h"
+
+static __device__ __attribute__((aligned(16))) unsigned int g_fast_zero16[4];  // zero source for K-tail DMA lanes
+
+struct FastP {
+  const bf16_t* A;
+  const bf16_t* B;
+  void* C;
+  const float* bias;      // fp32 [N] or null
+  const float* residual;  // fp32 [M, N] (ldc) or null
+  int M, N, K;
+  int lda, ldb, ldc;  // elements
+  int relu;
+  int tilesN, ntiles;
+  int nt_store;
+};
+
+__device__ __forceinline__ void fast_glds16(const void* src, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BN, bool OUT_F32, bool HAS_RES>
+__global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
+  constexpr int BM = 256, BK = 64, NW = 8, TM = 64, TN = BN / 2, WM = TM / 16, WN = TN / 16;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int B_INSTR = BN / 8;                  // wave-level DMA instructions per B tile (8 rows x 128 B each)
+  constexpr int A_PW = 4, B_PW = (B_INSTR + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // DMA source offsets of this lane (bytes): row lane/8 of the instruction's 8 rows, logical chunk (lane%8)^(row&7)
+  const int lrow = lane >> 3;
+  const int c_log = (lane & 7) ^ lrow;
+  const unsigned a_lane = (unsigned)(lrow * p.lda + c_log * 8) * 2u;
+  const unsigned b_lane = (unsigned)(lrow * p.ldb + c_log * 8) * 2u;
+  const int nk = (p.K + BK - 1) / BK;
+  const bool k_tail = (p.K % BK) != 0;
+
+  auto stage = [&](int buf, int m0, int n0, int kt) {
+    char* a_lds = smem + buf * STAGE_BYTES;
+    char* b_lds = a_lds + A_BYTES;
+    const char* Ab = (const char*)p.A + ((int64_t)(m0 + wave * 8) * p.lda + kt * BK) * 2;
+    const char* Bb = (const char*)p.B + ((int64_t)(n0 + wave * 8) * p.ldb + kt * BK) * 2;
+    if (k_tail && kt == nk - 1) {
+      const bool kvalid = kt * BK + c_log * 8 < p.K;
+#pragma unroll
+      for (int t = 0; t < A_PW; ++t)
+        fast_glds16(kvalid ? Ab + (int64_t)t * 64 * p.lda * 2 + a_lane : (const char*)g_fast_zero16, a_lds + (t * NW + wave) * 1024);
+#pragma unroll
+      for (int t = 0; t < B_PW; ++t)
+        if ((B_INSTR % NW == 0) || t * NW + wave < B_INSTR)
+          fast_glds16(kvalid ? Bb + (int64_t)t * 64 * p.ldb * 2 + b_lane : (const char*)g_fast_zero16, b_lds + (t * NW + wave) * 1024);
+    } else {
+#pragma unroll
+      for (int t = 0; t < A_PW; ++t) fast_glds16(Ab + (int64_t)t * 64 * p.lda * 2 + a_lane, a_lds + (t * NW + wave) * 1024);
+#pragma unroll
+      for (int t = 0; t < B_PW; ++t)
+        if ((B_INSTR % NW == 0) || t * NW + wave < B_INSTR)
+          fast_glds16(Bb + (int64_t)t * 64 * p.ldb * 2 + b_lane, b_lds + (t * NW + wave) * 1024);
+    }
+  };
+
+  // ---- epilogue geometry (tile independent) ----------------------------------------------------------------
+  constexpr int ESZ = OUT_F32 ? 4 : 2;
+  constexpr int PITCHW = TN * ESZ + 16;
+  // strips of RP rows per wave overlay ONE stage buffer (the other one holds the next tile's first K step)
+  constexpr int RP = (NW * 32 * PITCHW <= STAGE_BYTES) ? 32 : ((NW * 16 * PITCHW <= STAGE_BYTES) ? 16 : 8);
+  static_assert(NW * RP * PITCHW <= STAGE_BYTES, "wave strips do not fit a stage buffer");
+  constexpr int CPRW = TN * ESZ / 16;  // 16-byte chunks per strip row
+  constexpr int EPC = 16 / ESZ;        // elements per chunk
+  constexpr int NCH = RP * CPRW;
+  constexpr int NIT = (NCH + 63) / 64;
+  constexpr int G = NIT < 4 ? NIT : 4;  // chunks in flight per lane
+  int soff[NIT], goff[NIT];
+#pragma unroll
+  for (int t = 0; t < NIT; ++t) {
+    const int idx = lane + 64 * t;
+    const int r = idx / CPRW, c = idx % CPRW;
+    soff[t] = r * PITCHW + c * 16;
+    goff[t] = r * p.ldc + c * EPC;
+  }
+  const float lo = p.relu ? 0.f : -INFINITY;
+
+  // ---- persistent tile walk ----------------------------------------------------------------------------------
+  // slot: XCD-aware position of this workgroup inside a round of gridDim.x tiles (workgroups b and b+8 share an XCD
+  // and get neighbouring tiles -> the N tiles of one activation row panel hit the same L2)
+  const int G_ = gridDim.x;
+  int slot;
+  {
+    const int bid = blockIdx.x, q = G_ >> 3, r = G_ & 7, x = bid & 7;
+    slot = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  int lid = slot;
+  if (lid >= p.ntiles) return;
+  int m0 = (lid / p.tilesN) * BM, n0 = (lid % p.tilesN) * BN;
+  int buf = 0;
+  stage(0, m0, n0, 0);
+
+  while (true) {
+    const int lid_next = lid + G_;
+    const bool has_next = lid_next < p.ntiles;
+    const int m0n = has_next ? (lid_next / p.tilesN) * BM : 0, n0n = has_next ? (lid_next % p.tilesN) * BN : 0;
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      f32x4 bc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bc = *(const f32x4*)(p.bias + n0 + wn * TN + j * 16 + 4 * fq);
+#pragma unroll
+      for (int i = 0; i < WM; ++i) acc[i][j] = bc;
+    }
+
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk)
+        stage(buf ^ 1, m0, n0, kt + 1);
+      else if (has_next)
+        stage(buf ^ 1, m0n, n0n, 0);
+      const char* a_lds = smem + buf * STAGE_BYTES;
+      const char* b_lds = a_lds + A_BYTES;
+      const bool half = k_tail && kt == nk - 1 && (p.K % BK) <= 32;  // tail of <= 32: the second MFMA half is all zeros
+#pragma unroll
+      for (int kk = 0; kk < BK / 32; ++kk) {
+        if (kk == 1 && half) break;
+        bf16x8 af[WM], bfr[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          const int row = wm * TM + i * 16 + fr;
+          af[i] = *(const bf16x8*)(a_lds + (row * 8 + ((kk * 4 + fq) ^ (row & 7))) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const int row = wn * TN + j * 16 + fr;
+          bfr[j] = *(const bf16x8*)(b_lds + (row * 8 + ((kk * 4 + fq) ^ (row & 7))) * 16);
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            // weight tile as MFMA-A, activation tile as MFMA-B: lane holds C[m = ..+fr][n = ..+4*fq .. +3]
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      buf ^= 1;
+    }
+
+    // ---- epilogue: strips overlay the buffer of the last K step (buf ^ 1 now); buf holds the next tile's step 0 ----
+    __syncthreads();  // every wave is done reading that buffer
+    {
+      char* const strip = smem + (buf ^ 1) * STAGE_BYTES + wave * (RP * PITCHW);
+      char* const Cw = (char*)p.C + ((int64_t)(m0 + wm * TM) * p.ldc + n0 + wn * TN) * ESZ;
+      const char* const Rw = HAS_RES ? (const char*)p.residual + ((int64_t)(m0 + wm * TM) * p.ldc + n0 + wn * TN) * 4 : nullptr;
+#pragma unroll
+      for (int r0 = 0; r0 < TM; r0 += RP) {
+        // write RP rows of the wave's block: MFMA row tile i covers rows 16*i .. 16*i+15 (row = fr)
+#pragma unroll
+        for (int ii = 0; ii < (RP >= 16 ? RP / 16 : 1); ++ii) {
+          const int i = r0 / 16 + ii;
+          const bool mine = RP >= 16 || (fr >> 3) == ((r0 >> 3) & 1);
+          if (mine) {
+            char* lrow = strip + (RP >= 16 ? ii * 16 + fr : (fr & 7)) * PITCHW;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+              const int nl = j * 16 + 4 * fq;
+              const float v0 = fmaxf(acc[i][j][0], lo), v1 = fmaxf(acc[i][j][1], lo);
+              const float v2 = fmaxf(acc[i][j][2], lo), v3 = fmaxf(acc[i][j][3], lo);
+              if constexpr (OUT_F32) {
+                *(f32x4*)(lrow + nl * 4) = (f32x4){v0, v1, v2, v3};
+              } else {
+                uint2 o;
+                o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
+                o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                *(uint2*)(lrow + nl * 2) = o;
+              }
+            }
+          }
+        }
+        // compiler fence: hipcc otherwise sinks the strip reads below into the lane-masked write block above (seen with
+        // the 8-row passes: only the writing half of the lanes then read the strip back)
+        asm volatile("" ::: "memory");
+        // read back 16-byte chunks of consecutive columns and store whole lines
+        char* const Cp = Cw + (int64_t)r0 * p.ldc * ESZ;
+        const char* const Rp = HAS_RES ? Rw + (int64_t)r0 * p.ldc * 4 : nullptr;
+#pragma unroll
+        for (int t0 = 0; t0 < NIT; t0 += G) {
+          f32x4 res[G], vv[G];
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            if constexpr (HAS_RES) {
+              res[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              if (t0 + g < NIT && (NCH % 64 == 0 || lane + 64 * (t0 + g) < NCH)) res[g] = *(const f32x4*)(Rp + (unsigned)goff[t0 + g] * 4u);
+            }
+          }
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+            if (t0 + g < NIT) vv[g] = *(const f32x4*)(strip + soff[t0 + g]);
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            if (t0 + g >= NIT || !(NCH % 64 == 0 || lane + 64 * (t0 + g) < NCH)) continue;
+            f32x4 v = vv[g];
+            if constexpr (HAS_RES) v += res[g];
+            f32x4* dst = (f32x4*)(Cp + (unsigned)goff[t0 + g] * (unsigned)ESZ);
+            if (p.nt_store)
+              __builtin_nontemporal_store(v, dst);
+            else
+              *dst = v;
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    lid = lid_next;
+    m0 = m0n;
+    n0 = n0n;
+  }
+}
+
+template <int BN, bool OUT_F32, bool HAS_RES>
+static int launch_fast(const FastP& p, hipStream_t s) {
+  constexpr int STAGE = (256 + BN) * 64 * 2;
+  auto k = gemm_fast_kernel<BN, OUT_F32, HAS_RES>;
+  static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  (void)once;
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RF_EINVAL;
+    n_cu = prop.multiProcessorCount;
+  }
+  const int grid = p.ntiles < n_cu ? p.ntiles : n_cu;
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), 2 * STAGE, s, p);
+  return rf_launch_status();
+}
+
+// Returns 1 and launches when the descriptor fits the persistent fast path, 0 when it does not (the caller then uses the
+// generic kernel), a negative / HIP error code when the launch failed.
+int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream) {
+  *rc = 0;
+  if (getenv("RF_NO_FAST_GEMM")) return 0;
+  if (d.ab_dtype != RF_BF16 || d.a_mode != RF_AMODE_PLAIN || batch != 1) return 0;
+  if (d.a_rc > 0 || d.b_rc > 0 || d.c_rc > 0 || d.c_cc > 0 || d.kc != d.K) return 0;
+  if (d.M % 256 != 0 || d.M < 16384 || d.K < 64 || d.K % 8 != 0 || d.alpha != 1.0f) return 0;
+  if (d.bias_mode == RF_BIAS_ROW || (d.act != RF_ACT_NONE && d.act != RF_ACT_RELU) || d.ln_out) return 0;
+  if (d.a_ri % 8 || d.b_ri % 8 || d.c_ri % 8 || ((uintptr_t)d.A % 16) || ((uintptr_t)d.B % 16) || ((uintptr_t)d.C % 16)) return 0;
+  if (d.bias_mode == RF_BIAS_COL && ((uintptr_t)d.bias % 16)) return 0;
+  if (d.residual && (d.c_dtype != RF_F32 || ((uintptr_t)d.residual % 16))) return 0;
+  if ((int64_t)256 * d.a_ri >= (1ll << 30) || (int64_t)64 * d.c_ri >= (1ll << 28)) return 0;  // 32-bit lane offsets
+  const int bn = d.N % 256 == 0 ? 256 : (d.N % 288 == 0 ? 288 : (d.N % 192 == 0 ? 192 : (d.N % 128 == 0 ? 128 : 0)));
+  if (!bn) return 0;
+  FastP p;
+  p.A = (const bf16_t*)d.A;
+  p.B = (const bf16_t*)d.B;
+  p.C = d.C;
+  p.bias = d.bias_mode == RF_BIAS_COL ? d.bias : nullptr;
+  p.residual = d.residual;
+  p.M = d.M; p.N = d.N; p.K = d.K;
+  p.lda = (int)d.a_ri; p.ldb = (int)d.b_ri; p.ldc = (int)d.c_ri;
+  p.relu = d.act == RF_ACT_RELU;
+  p.tilesN = d.N / bn;
+  const int64_t nt = (int64_t)(d.M / 256) * p.tilesN;
+  if (nt > 0x7fffffffLL) return 0;
+  p.ntiles = (int)nt;
+  p.nt_store = ((int64_t)d.M * d.N * (d.c_dtype == RF_F32 ? 4 : 2) > (64ll << 20)) && !getenv("RF_NO_NT_STORE");
+  hipStream_t s = (hipStream_t)stream;
+  const bool f32 = d.c_dtype == RF_F32, res = d.residual != nullptr;
+#define RF_FAST(BN_)                                                   \
+  if (bn == BN_) {                                                     \
+    if (!f32) *rc = launch_fast<BN_, false, false>(p, s);              \
+    else if (res) *rc = launch_fast<BN_, true, true>(p, s);            \
+    else *rc = launch_fast<BN_, true, false>(p, s);                    \
+    return 1;                                                          \
+  }
+  RF_FAST(256)
+  RF_FAST(288)
+  RF_FAST(192)
+  RF_FAST(128)
+#undef RF_FAST
+  return 0;
+}

@@ -39,7 +39,40 @@ def test_linear(dtype, tol, M, N, K):
     assert rel_err(y, torch.relu(ref) + res) < tol
 
 
-@pytest.mark.parametrize("cfg", list(range(1, 25)))
+@pytest.mark.parametrize("M,N,K", [(16384, 256, 288), (16384, 1536, 288), (32768, 288, 512), (16384, 288, 1152),
+                                   (16384, 384, 768), (16384, 1152, 384), (16384, 128, 64), (16384, 384, 72),
+                                   (65536 + 256, 512, 96), (16384, 2304, 384), (16384, 576, 128)])
+def test_gemm_persistent_fast_path(M, N, K):
+    """Plain row-major panels with M % 256 == 0 take the persistent kernel (gemm_fast.hip): every output type /
+    bias / ReLU / residual specialisation, K tails of 8..56, more tiles than CUs and fewer."""
+    x, w, b = randn(M, K, dtype=torch.bfloat16), randn(N, K, dtype=torch.bfloat16, seed=1), randn(N, seed=2)
+    ref = x.float() @ w.float().t()
+    y = ops.linear(x, w, None, out_dtype=torch.bfloat16)
+    assert rel_err(y, ref) < 2e-2
+    y = ops.linear(x, w, b, out_dtype=torch.bfloat16, act=L.ACT_RELU)
+    assert rel_err(y, torch.relu(ref + b)) < 2e-2
+    y = ops.linear(x, w, b, out_dtype=torch.float32)
+    assert rel_err(y, ref + b) < 2e-2
+    res = randn(M, N, seed=3)
+    y = ops.linear(x, w, b, out_dtype=torch.float32, residual=res)
+    assert rel_err(y, ref + b + res) < 2e-2
+    # the generic kernel (explicit tile) must agree with it to fp32 rounding on the same bf16 operands
+    y2 = ops.linear(x, w, b, out_dtype=torch.float32, residual=res, tile_cfg=13 if N % 256 == 0 else 1)
+    assert rel_err(y, y2) < 1e-5
+
+
+def test_gemm_persistent_exact_integers():
+    """Small-integer operands: any row / column / K-chunk mix-up of the persistent kernel shows up exactly."""
+    M, N, K = 16384, 288, 136
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randint(-3, 4, (M, K), generator=g).to(DEV).bfloat16()
+    w = torch.randint(-3, 4, (N, K), generator=g).to(DEV).bfloat16()
+    for od in (torch.float32, torch.bfloat16):
+        y = ops.linear(x, w, None, out_dtype=od)
+        assert torch.equal(y.float(), x.float() @ w.float().t())
+
+
+@pytest.mark.parametrize("cfg", list(range(1, 19)))
 def test_gemm_all_tile_configs(cfg):
     M, N, K = 777, 600, 352
     x, w = randn(M, K, dtype=torch.bfloat16), randn(N, K, dtype=torch.bfloat16, seed=1)

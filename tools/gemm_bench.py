@@ -42,11 +42,11 @@ def main():
         out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
         fl = 2.0 * M * N * K
         t = timeit(lambda: torch.nn.functional.linear(x, w, b.bfloat16()))
-        line = f"{tag:14s} M={M:7d} N={N:5d} K={K:5d} torch {fl / t / 1e9:7.1f} TF/s |"
+        line = f"{tag:14s} M={M:7d} N={N:5d} K={K:5d} torch {fl / t / 1e9:7.1f} TF/s {t * 1e3:6.0f}us |"
         for c in cfgs:
             try:
                 t = timeit(lambda: ops.linear(x, w, b, out=out, tile_cfg=c))
-                line += f" cfg{c}:{fl / t / 1e9:6.1f}"
+                line += f" cfg{c}:{fl / t / 1e9:6.1f} ({t * 1e3:4.0f}us)"
             except Exception as ex:  # noqa: BLE001
                 line += f" cfg{c}:ERR"
         print(line, flush=True)
