@@ -249,6 +249,7 @@ int rf_coord_apply(const float* xyz, const float* disp, float* xyz_out, int64_t 
 /* Library self-description */
 /* Timing experiments only: when buf is non-null every bf16 rf_gemm workgroup records 8 x uint64 phase stamps into it. */
 int rf_debug_gemm_stamps(void* buf);
+int rf_debug_gemm_fast_stamps(void* buf);
 
 int rf_version(void);
 const char* rf_build_info(void);

@@ -70,6 +70,7 @@ PROTOTYPES = {
     "rf_center_ca": [vp, vp, i64, vp],
     "rf_scale_rows": [vp, i32, vp, i64, i32, vp],
     "rf_debug_gemm_stamps": [vp],
+    "rf_debug_gemm_fast_stamps": [vp],
     "rf_version": [],
 }
 

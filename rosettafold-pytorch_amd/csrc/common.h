@@ -49,3 +49,4 @@ static inline int rf_launch_status() {
 
 // gemm_fast.hip: persistent plain-layout bf16 GEMM; returns 1 (launched, *rc = status) or 0 (descriptor does not fit)
 int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream);
+void rf_gemm_fast_set_stamps(void* buf);

@@ -78,7 +78,7 @@ __host__ __device__ constexpr int lds_bytes_for(int bm, int bn, int bk, int wgm)
 template <int BK>
 __device__ __forceinline__ int swz(int row) {
   if constexpr (BK == 64)
-    return row & 7;  // 8 x 16B chunks per 128-B row
+    return (row >> 1) & 7;  // 8 x 16B chunks per 128-B row, two rows per 256-B bank row: the 16 rows of a fragment read hit 16 distinct slots
   else
     return (0x78 >> (((row >> 2) & 3) * 2)) & 3;  // 4 chunks per 64-B row: g = {0,2,3,1}[(row>>2)&3]
 }
@@ -154,7 +154,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_bf16_kernel(const Gemm
   }
   // logical K chunk this lane fetches (same for all its slots: see header comment)
   const int row_in_instr = lane / SPR;
-  const int c_log = (lane % SPR) ^ swz<BK>(row_in_instr);
+  // (BK = 64: an instruction covers 8 rows, the swizzle period is 16 rows -> the instruction's parity, = the wave's, enters)
+  const int c_log = (lane % SPR) ^ swz<BK>(row_in_instr + (BK == 64 ? 8 * (wave & 1) : 0));
   int kpos = c_log * 8;                    // logical k of this lane's chunk in the current K step
   int kq = kpos / d.kc, kr = kpos % d.kc;  // chunk index / offset within chunk
   int a_koff = 0, b_koff = kq * (int)d.b_ko + kr, cdi = 0, cdj = 0;
@@ -604,6 +605,12 @@ extern "C" int rf_debug_gemm_stamps(void* buf) {
   g_gemm_stamps = (unsigned long long*)buf;
   return 0;
 }
+/* same for the persistent kernel of gemm_fast.hip: {cycles total, in vmcnt waits, in barriers, in K-step bodies, in
+ * epilogues, tiles, -, -} per workgroup (shader clock) */
+extern "C" int rf_debug_gemm_fast_stamps(void* buf) {
+  rf_gemm_fast_set_stamps(buf);
+  return 0;
+}
 
 extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   if (!dd || !dd->A || !dd->B || !dd->C) return RF_EINVAL;
@@ -677,7 +684,7 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   if (!al8(d.b_ri) || !al8(d.b_ro) || !al8(d.b_ko) || !al8(d.b_bs[0]) || !al8(d.b_bs[1]) || !al8(d.b_bs[2]))
     return RF_EALIGN;
 
-  if (d.tile_cfg == 0 && !p.dbg && !p.stamps) {
+  if (d.tile_cfg == 0 && !p.dbg && !p.stamps) {  // (stamps of the generic kernel: keep it on the generic kernel)
     int rc = 0;
     if (rf_gemm_fast_try(d, batch, &rc, stream)) return rc;
   }

@@ -30,6 +30,7 @@ struct FastP {
   int relu;
   int tilesN, ntiles;
   int nt_store;
+  unsigned long long* stamps;  // timing experiments (tools/gemm_stamps.py): 8 x u64 per workgroup, else null
 };
 
 __device__ __forceinline__ void fast_glds16(const void* src, void* lds_wave_base) {
@@ -37,7 +38,7 @@ __device__ __forceinline__ void fast_glds16(const void* src, void* lds_wave_base
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BN, bool OUT_F32, bool HAS_RES>
+template <int BN, bool OUT_F32, bool HAS_RES, bool STAMP = false>
 __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
   constexpr int BM = 256, BK = 64, NW = 8, TM = 64, TN = BN / 2, WM = TM / 16, WN = TN / 16;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -51,9 +52,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fq = lane >> 4;
 
-  // DMA source offsets of this lane (bytes): row lane/8 of the instruction's 8 rows, logical chunk (lane%8)^(row&7)
+  // DMA source offsets of this lane (bytes): row lane/8 of the instruction's 8 rows; the LDS image is lane-linear, so the
+  // bank swizzle (chunk ^ ((row >> 1) & 7): the 16 rows of one fragment read then hit 16 distinct 16-byte slots of the
+  // 256-byte bank row) is applied to the SOURCE chunk and again on the ds_read
   const int lrow = lane >> 3;
-  const int c_log = (lane & 7) ^ lrow;
+  const int c_log = (lane & 7) ^ ((4 * (wave & 1) + (lrow >> 1)) & 7);  // swizzle ((row >> 1) & 7) of tile row 8 * instr + lrow
   const unsigned a_lane = (unsigned)(lrow * p.lda + c_log * 8) * 2u;
   const unsigned b_lane = (unsigned)(lrow * p.ldb + c_log * 8) * 2u;
   const int nk = (p.K + BK - 1) / BK;
@@ -115,6 +118,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
   }
   int lid = slot;
   if (lid >= p.ntiles) return;
+  unsigned long long tk_vm = 0, tk_bar = 0, tk_mma = 0, tk_epi = 0, tk_0 = 0, tk_x = 0, ntile = 0;
+  if constexpr (STAMP) tk_0 = clock64();
   int m0 = (lid / p.tilesN) * BM, n0 = (lid % p.tilesN) * BN;
   int buf = 0;
   stage(0, m0, n0, 0);
@@ -134,8 +139,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
     }
 
     for (int kt = 0; kt < nk; ++kt) {
+      if constexpr (STAMP) tk_x = clock64();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (STAMP) { const unsigned long long t = clock64(); tk_vm += t - tk_x; tk_x = t; }
       __syncthreads();
+      if constexpr (STAMP) { const unsigned long long t = clock64(); tk_bar += t - tk_x; tk_x = t; }
       if (kt + 1 < nk)
         stage(buf ^ 1, m0, n0, kt + 1);
       else if (has_next)
@@ -150,12 +158,12 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
           const int row = wm * TM + i * 16 + fr;
-          af[i] = *(const bf16x8*)(a_lds + (row * 8 + ((kk * 4 + fq) ^ (row & 7))) * 16);
+          af[i] = *(const bf16x8*)(a_lds + (row * 8 + ((kk * 4 + fq) ^ ((row >> 1) & 7))) * 16);
         }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
           const int row = wn * TN + j * 16 + fr;
-          bfr[j] = *(const bf16x8*)(b_lds + (row * 8 + ((kk * 4 + fq) ^ (row & 7))) * 16);
+          bfr[j] = *(const bf16x8*)(b_lds + (row * 8 + ((kk * 4 + fq) ^ ((row >> 1) & 7))) * 16);
         }
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -165,7 +173,12 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
       buf ^= 1;
+      if constexpr (STAMP) {
+        asm volatile("s_nop 0" ::: "memory");
+        tk_mma += clock64() - tk_x;
+      }
     }
+    if constexpr (STAMP) tk_x = clock64();
 
     // ---- epilogue: strips overlay the buffer of the last K step (buf ^ 1 now); buf holds the next tile's step 0 ----
     __syncthreads();  // every wave is done reading that buffer
@@ -231,17 +244,27 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
         }
       }
     }
+    if constexpr (STAMP) {
+      tk_epi += clock64() - tk_x;
+      ++ntile;
+    }
     if (!has_next) break;
     lid = lid_next;
     m0 = m0n;
     n0 = n0n;
   }
+  if constexpr (STAMP) {
+    if (tid == 0 && p.stamps) {
+      unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
+      o[0] = clock64() - tk_0; o[1] = tk_vm; o[2] = tk_bar; o[3] = tk_mma; o[4] = tk_epi; o[5] = ntile; o[6] = 0; o[7] = 0;
+    }
+  }
 }
 
-template <int BN, bool OUT_F32, bool HAS_RES>
+template <int BN, bool OUT_F32, bool HAS_RES, bool STAMP = false>
 static int launch_fast(const FastP& p, hipStream_t s) {
   constexpr int STAGE = (256 + BN) * 64 * 2;
-  auto k = gemm_fast_kernel<BN, OUT_F32, HAS_RES>;
+  auto k = gemm_fast_kernel<BN, OUT_F32, HAS_RES, STAMP>;
   static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
   static int n_cu = 0;
@@ -255,6 +278,9 @@ static int launch_fast(const FastP& p, hipStream_t s) {
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), 2 * STAGE, s, p);
   return rf_launch_status();
 }
+
+static unsigned long long* g_fast_stamps = nullptr;
+void rf_gemm_fast_set_stamps(void* buf) { g_fast_stamps = (unsigned long long*)buf; }
 
 // Returns 1 and launches when the descriptor fits the persistent fast path, 0 when it does not (the caller then uses the
 // generic kernel), a negative / HIP error code when the launch failed.
@@ -287,6 +313,11 @@ int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
   p.nt_store = ((int64_t)d.M * d.N * (d.c_dtype == RF_F32 ? 4 : 2) > (64ll << 20)) && !getenv("RF_NO_NT_STORE");
   hipStream_t s = (hipStream_t)stream;
   const bool f32 = d.c_dtype == RF_F32, res = d.residual != nullptr;
+  p.stamps = g_fast_stamps;
+  if (p.stamps && bn == 256 && !f32) {  // timing experiment: instrumented twin of the bf16-output 256-wide kernel
+    *rc = launch_fast<256, false, false, true>(p, s);
+    return 1;
+  }
 #define RF_FAST(BN_)                                                   \
   if (bn == BN_) {                                                     \
     if (!f32) *rc = launch_fast<BN_, false, false>(p, s);              \

@@ -18,6 +18,21 @@ def main():
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     nblk = 65536
     stamps = torch.zeros(nblk, 8, device="cuda", dtype=torch.int64)
+    if os.environ.get("FAST"):
+        for _ in range(3):
+            ops.linear(x, w, None, out=out)
+        torch.cuda.synchronize()
+        L.lib.rf_debug_gemm_fast_stamps(stamps.data_ptr())
+        ops.linear(x, w, None, out=out)
+        torch.cuda.synchronize()
+        L.lib.rf_debug_gemm_fast_stamps(None)
+        s = stamps.cpu().numpy()
+        s = s[s[:, 0] != 0].astype(np.float64)
+        nt = s[:, 5].mean()
+        print(f"persistent kernel: {len(s)} workgroups, {nt:.1f} tiles each, total {s[:, 0].mean():.0f} cycles = {s[:, 0].mean() / nt:.0f} per tile")
+        for name, col in zip(["vmcnt wait", "barrier", "K-step body", "epilogue"], [1, 2, 3, 4]):
+            print(f"  {name:12s} {s[:, col].mean() / nt:8.0f} cycles/tile  ({100 * s[:, col].mean() / s[:, 0].mean():.1f} %)")
+        return
     for _ in range(3):
         ops.linear(x, w, None, out=out, tile_cfg=cfg)
     torch.cuda.synchronize()
