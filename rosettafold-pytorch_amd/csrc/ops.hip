@@ -139,6 +139,125 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int6
   }
 }
 
+
+// bf16-input twin (the 1024-wide outer-product rows, rf.py:416): 16-byte loads of 8 bf16, NCH chunks per lane
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_vec_bf16_kernel(const bf16_t* x, int64_t x_ld, void* y, int y_dt, int64_t y_ld,
+                                                                 int64_t rows, int D, const float* gamma, const float* beta,
+                                                                 float eps) {
+  const int lane = threadIdx.x & 63;
+  const int nch = D >> 3;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t row = wid; row < rows; row += nw) {
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+      const int c = lane + 64 * t;
+      uint4 u = make_uint4(0u, 0u, 0u, 0u);
+      if (c < nch) u = *(const uint4*)(x + row * x_ld + 8 * c);
+      const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[t][2 * e] = __uint_as_float(w[e] << 16);
+        v[t][2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+        s += v[t][2 * e] + v[t][2 * e + 1];
+      }
+    }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < NCH; ++t)
+      if (lane + 64 * t < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = v[t][e] - mean;
+          q += a * a;
+        }
+      }
+    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+      const int c = lane + 64 * t;
+      if (c < nch) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[t][e] - mean) * rstd;
+        if (gamma) {
+          const float4 g0 = *(const float4*)(gamma + 8 * c), g1 = *(const float4*)(gamma + 8 * c + 4);
+          const float4 b0 = *(const float4*)(beta + 8 * c), b1 = *(const float4*)(beta + 8 * c + 4);
+          o[0] = o[0] * g0.x + b0.x; o[1] = o[1] * g0.y + b0.y; o[2] = o[2] * g0.z + b0.z; o[3] = o[3] * g0.w + b0.w;
+          o[4] = o[4] * g1.x + b1.x; o[5] = o[5] * g1.y + b1.y; o[6] = o[6] * g1.z + b1.z; o[7] = o[7] * g1.w + b1.w;
+        }
+        if (y_dt == RF_F32) {
+          float* yp = (float*)y + row * y_ld + 8 * c;
+          *(float4*)yp = make_float4(o[0], o[1], o[2], o[3]);
+          *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        } else {
+          uint4 w;
+          w.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+          w.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+          w.z = (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16);
+          w.w = (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16);
+          *(uint4*)((bf16_t*)y + row * y_ld + 8 * c) = w;
+        }
+      }
+    }
+  }
+}
+
+// Narrow rows (D = 32 or 64, fp32 in: the d_proj / d_state / radial-MLP norms): LPR = D/4 lanes per row, 64/LPR rows per
+// wave instruction, float4 per lane, statistics reduced inside the LPR-lane group.
+template <int LPR>
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* x, int64_t x_ld, void* y, int y_dt, int64_t y_ld,
+                                                               int64_t rows, const float* gamma, const float* beta, float eps,
+                                                               int groups, int act) {
+  constexpr int D = 4 * LPR, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / LPR, c = lane % LPR;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t r0 = wid * RPW; r0 < rows; r0 += nw * RPW) {
+    const int64_t row = r0 + sub;
+    const bool ok = row < rows;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) v = *(const float4*)(x + row * x_ld + 4 * c);
+    float s = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / D;
+    const float a0 = v.x - mean, a1 = v.y - mean, a2 = v.z - mean, a3 = v.w - mean;
+    float q = (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / D + eps);
+    if (ok) {
+      float o[4] = {a0 * rstd, a1 * rstd, a2 * rstd, a3 * rstd};
+      if (gamma) {
+        const int64_t gb = (groups > 1 ? (row % groups) * D : 0) + 4 * c;
+        const float4 g = *(const float4*)(gamma + gb), b = *(const float4*)(beta + gb);
+        o[0] = o[0] * g.x + b.x; o[1] = o[1] * g.y + b.y; o[2] = o[2] * g.z + b.z; o[3] = o[3] * g.w + b.w;
+      }
+      if (act == RF_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+      } else if (act == RF_ACT_LEAKY) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.01f * o[e];
+      }
+      if (y_dt == RF_F32) {
+        *(float4*)((float*)y + row * y_ld + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        uint2 w;
+        w.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+        w.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+        *(uint2*)((bf16_t*)y + row * y_ld + 4 * c) = w;
+      }
+    }
+  }
+}
+
 template <bool SYM>
 static int launch_ln(const void* x, int x_dt, int64_t x_ld, void* y, int y_dt, int64_t y_ld, int64_t rows, int D,
                      const float* g, const float* b, float eps, int L, int groups, int act, hipStream_t s) {
@@ -150,6 +269,22 @@ static int launch_ln(const void* x, int x_dt, int64_t x_ld, void* y, int y_dt, i
       hipLaunchKernelGGL((layernorm_vec_kernel<2>), dim3(gv), dim3(256), 0, s, (const float*)x, x_ld, y, y_dt, y_ld, rows, D, g, b, eps, act);
     else
       hipLaunchKernelGGL((layernorm_vec_kernel<4>), dim3(gv), dim3(256), 0, s, (const float*)x, x_ld, y, y_dt, y_ld, rows, D, g, b, eps, act);
+    return rf_launch_status();
+  }
+  const bool al16 = ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (!g || (((uintptr_t)g % 16) == 0 && ((uintptr_t)b % 16) == 0));
+  if (!SYM && x_dt == RF_BF16 && groups <= 1 && act == RF_ACT_NONE && D % 8 == 0 && D > 512 && D <= 1024 && x_ld % 8 == 0 &&
+      y_ld % 8 == 0 && al16) {
+    const unsigned gv = (unsigned)(rows < 8192 ? cdiv(rows, 4) : 2048);
+    hipLaunchKernelGGL((layernorm_vec_bf16_kernel<2>), dim3(gv), dim3(256), 0, s, (const bf16_t*)x, x_ld, y, y_dt, y_ld, rows, D, g, b, eps);
+    return rf_launch_status();
+  }
+  if (!SYM && x_dt == RF_F32 && (D == 32 || D == 64) && x_ld % 4 == 0 && y_ld % 4 == 0 && al16) {
+    const int rpb = 4 * (256 / D);  // rows per workgroup pass
+    const unsigned gv = (unsigned)(rows < (int64_t)rpb * 4096 ? cdiv(rows, rpb) : 4096);
+    if (D == 32)
+      hipLaunchKernelGGL((layernorm_narrow_kernel<8>), dim3(gv), dim3(256), 0, s, (const float*)x, x_ld, y, y_dt, y_ld, rows, g, b, eps, groups, act);
+    else
+      hipLaunchKernelGGL((layernorm_narrow_kernel<16>), dim3(gv), dim3(256), 0, s, (const float*)x, x_ld, y, y_dt, y_ld, rows, g, b, eps, groups, act);
     return rf_launch_status();
   }
   const dim3 grid(cdiv(rows, 4)), blk(256);

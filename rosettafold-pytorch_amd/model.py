@@ -35,6 +35,24 @@ class _Runtime:
     dtype = torch.bfloat16
     fused_favor = True  # use the fused FAVOR+ kernel when the shape allows (bf16, dim_head 64, seq 128/256)
     head_major_qkv = bool(int(__import__("os").environ.get("RF_HEAD_MAJOR_QKV", "0")))
+    # Producer -> consumer chains whose intermediate (q|k|v, feed-forward hidden) is larger than this many bytes are run
+    # panel by panel, so the intermediate panel is still in the 256 MB Infinity Cache when its consumer reads it
+    # (tools/mall_chunk_bench.py: projection + FAVOR alone 958 -> 842 us at 200 MB panels; inside the full forward the
+    # step time did not move, 432 vs 437 ms, so it is opt-in: RF_MALL_PANEL_MB=208).  0 disables.
+    mall_panel_bytes = int(__import__("os").environ.get("RF_MALL_PANEL_MB", "0")) << 20
+
+
+def row_panels(rows, bytes_per_row, unit):
+    """Split `rows` into equal panels of whole `unit`s (unit % 256 == 0 keeps every panel on the persistent GEMM path) whose
+    intermediate stays under RT.mall_panel_bytes.  Returns the panel length (== rows when no split applies)."""
+    cap = RT.mall_panel_bytes
+    if cap <= 0 or rows * bytes_per_row <= cap or rows % unit:
+        return rows
+    units = rows // unit
+    for n in range(2, units + 1):
+        if units % n == 0 and (rows // n) * bytes_per_row <= cap and (rows // n) >= 16384:
+            return rows // n
+    return rows
 
 
 RT = _Runtime()
@@ -124,8 +142,18 @@ class FeedForward(RFModule):
     def apply_residual(self, xn, x_res, next_ln=None):
         """x_res += W2 relu(W1 xn + b1) + b2   (x_res fp32, in place).  With `next_ln` the second GEMM's epilogue also
         emits next_ln(x_res) (returned, or None when the fused form does not apply)."""
-        h = ops.linear(xn, self.wt("w1", self.net[0]), _f(self.net[0].bias), act=L.ACT_RELU)
-        return ops.linear_residual_ln(h, self.wt("w2", self.net[3]), _f(self.net[3].bias), x_res, next_ln)
+        w1, b1, w2, b2 = self.wt("w1", self.net[0]), _f(self.net[0].bias), self.wt("w2", self.net[3]), _f(self.net[3].bias)
+        d_ff, R = w1.shape[0], xn.numel() // xn.shape[-1]
+        pr = row_panels(R, d_ff * xn.element_size(), 256) if x_res.is_contiguous() and xn.is_contiguous() else R
+        if pr < R:  # hidden panel stays in the Infinity Cache between the two GEMMs
+            xn2, xr2 = xn.view(R, -1), x_res.view(R, -1)
+            h = torch.empty(pr, d_ff, device=xn.device, dtype=xn.dtype)
+            for r0 in range(0, R, pr):
+                ops.linear(xn2[r0:r0 + pr], w1, b1, act=L.ACT_RELU, out=h)
+                ops.linear(h, w2, b2, out=xr2[r0:r0 + pr], residual=xr2[r0:r0 + pr])
+            return None
+        h = ops.linear(xn, w1, b1, act=L.ACT_RELU)
+        return ops.linear_residual_ln(h, w2, b2, x_res, next_ln)
 
     def forward(self, x):
         xn = ops.cast(x.contiguous(), T())
@@ -401,6 +429,20 @@ class PerformerSelfAttention(RFModule):
                 ops.favor_attention(qkv, pcf, o, (Lo * so_c, so_c, dh, Ls * dh), (RB * inner, so * inner, ss * inner),
                                     0, H * Ls * dh, 2 * H * Ls * dh, B, Lo, H, Ls, dh, m, not gen, eps)
             else:
+                # whole batch elements per panel (RB rows each: any axis stays addressable inside one element)
+                pr = row_panels(R, W3 * 2, RB)
+                if pr < R:
+                    nb = pr // RB
+                    qkv = torch.empty(pr, W3, device=dev, dtype=T())
+                    xn2, xr2 = xn.view(R, D), x_res.view(R, -1)
+                    wo, bo = self.wt("o", self.to_out), _f(self.to_out.bias)
+                    for r0 in range(0, R, pr):
+                        ops.linear(xn2[r0:r0 + pr], wqkv, None, out=qkv)
+                        op = o[r0:r0 + pr]
+                        ops.favor_attention(qkv, pcf, op, (RB * W3, so * W3, ss * W3, dh), (RB * inner, so * inner, ss * inner),
+                                            0, inner, 2 * inner, nb, Lo, H, Ls, dh, m, not gen, eps)
+                        ops.linear(op, wo, bo, out=xr2[r0:r0 + pr], residual=xr2[r0:r0 + pr])
+                    return None
                 qkv = ops.linear(xn, wqkv, None)
                 ops.favor_attention(qkv, pcf, o, (RB * W3, so * W3, ss * W3, dh), (RB * inner, so * inner, ss * inner),
                                     0, inner, 2 * inner, B, Lo, H, Ls, dh, m, not gen, eps)

@@ -180,6 +180,37 @@ def test_layernorm(D, dtype):
     assert rel_err(y, ref) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
 
 
+@pytest.mark.parametrize("D,rows", [(1024, 1000), (768, 333), (1024, 20000)])
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+def test_layernorm_wide_bf16_rows(D, rows, odt):
+    """bf16 rows of 513..1024 (the outer-product LayerNorm, rf.py:416) take the 16-byte vectorised kernel."""
+    x = (randn(rows, D) * 3 + 1).bfloat16()
+    g, b = randn(D, seed=1), randn(D, seed=2)
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), g, b)
+    y = ops.layernorm(x, g, b, out_dtype=odt)
+    assert rel_err(y, ref) < (1e-2 if odt == torch.bfloat16 else 1e-5)
+
+
+@pytest.mark.parametrize("D", [32, 64])
+@pytest.mark.parametrize("odt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows", [5, 1001, 70000])
+def test_layernorm_narrow_rows(D, odt, rows):
+    """fp32 rows of 32 / 64 values: several rows per wave instruction; plus the grouped affine + LeakyReLU form of the
+    SE(3) radial MLPs (ea/modules.py:265-275)."""
+    x = randn(rows, D) * 3 + 1
+    g, b = randn(D, seed=1), randn(D, seed=2)
+    ref = torch.nn.functional.layer_norm(x, (D,), g, b)
+    y = ops.layernorm(x, g, b, out_dtype=odt)
+    assert rel_err(y, ref) < (1e-2 if odt == torch.bfloat16 else 1e-5)
+    if odt == torch.float32 and rows >= 8:
+        G = 8
+        gg, bb = randn(G, D, seed=3), randn(G, D, seed=4)
+        idx = torch.arange(rows, device=DEV) % G
+        ref = torch.nn.functional.leaky_relu(torch.nn.functional.layer_norm(x, (D,)) * gg[idx] + bb[idx], 0.01)
+        y = ops.layernorm(x, gg, bb, out_dtype=odt, groups=G, act=L.ACT_LEAKY)
+        assert rel_err(y, ref) < 1e-5
+
+
 def test_softmax_and_tied():
     B, H, Lr = 2, 3, 50
     lg = randn(B, H, Lr, Lr) * 4
