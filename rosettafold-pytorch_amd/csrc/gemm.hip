@@ -29,6 +29,7 @@ struct GemmP {
   int stage_epi;  // 1: C tile goes through LDS and is written as whole rows (16-byte coalesced stores)
   int nt_store;   // 1: streaming (nontemporal) stores for large outputs
   int c_pow2, c_rsh, c_csh;  // C split factors are powers of two: shift amounts
+  int f32_vec;    // fp32 kernel: bit 0 / 1 = A / B tiles can be staged with float4 loads
   unsigned long long* stamps;  // timing experiments: per-workgroup phase stamps (rf_debug_gemm_stamps), else null
 };
 
@@ -489,14 +490,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // plain row-major operands with K % 4 == 0 (the SE(3) / structure-track projections): one float4 per thread and tile
+  const bool a_vec = p.f32_vec & 1, b_vec = p.f32_vec & 2;
+  const int vr = tid >> 2, vk = (tid & 3) * 4;
   for (int k0 = 0; k0 < d.K; k0 += BK) {
-    for (int e = tid; e < BM * BK; e += 256) {
-      const int r = e / BK, kk = e % BK;
-      As[kk][r] = a_elem_f32(d, Ab, m0 + r, k0 + kk);
-      const int n = n0 + r, k = k0 + kk;
-      Bs[kk][r] = (n < d.N && k < d.K)
-                      ? Bb[split_off(n, d.b_rc, d.b_ro, d.b_ri) + (int64_t)(k / d.kc) * d.b_ko + (k % d.kc)]
-                      : 0.f;
+    if (a_vec) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + vr < d.M && k0 + vk < d.K) v = *(const float4*)(Ab + (int64_t)(m0 + vr) * d.a_ri + k0 + vk);
+      As[vk][vr] = v.x; As[vk + 1][vr] = v.y; As[vk + 2][vr] = v.z; As[vk + 3][vr] = v.w;
+    }
+    if (b_vec) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n0 + vr < d.N && k0 + vk < d.K) v = *(const float4*)(Bb + (int64_t)(n0 + vr) * d.b_ri + k0 + vk);
+      Bs[vk][vr] = v.x; Bs[vk + 1][vr] = v.y; Bs[vk + 2][vr] = v.z; Bs[vk + 3][vr] = v.w;
+    }
+    if (!a_vec || !b_vec) {
+      for (int e = tid; e < BM * BK; e += 256) {
+        const int r = e / BK, kk = e % BK;
+        if (!a_vec) As[kk][r] = a_elem_f32(d, Ab, m0 + r, k0 + kk);
+        const int n = n0 + r, k = k0 + kk;
+        if (!b_vec)
+          Bs[kk][r] = (n < d.N && k < d.K)
+                          ? Bb[split_off(n, d.b_rc, d.b_ro, d.b_ri) + (int64_t)(k / d.kc) * d.b_ko + (k % d.kc)]
+                          : 0.f;
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -523,6 +540,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
     const int64_t c_row = c_z + split_off(m, d.c_rc, d.c_ro, d.c_ri);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      const int nb = n0 + wc * 32 + j * 16 + 4 * fq;
+      if (p.vec_store && d.c_cc <= 0 && nb + 3 < d.N) {  // 16-byte (fp32) / 8-byte (bf16) store of the lane's 4 columns
+        const int64_t o = c_row + nb;
+        float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d.bias_mode == RF_BIAS_COL) bc = *(const float4*)(d.bias + nb);
+        const float bm = d.bias_mode == RF_BIAS_ROW ? d.bias[m] : 0.f;
+        const float bv[4] = {bc.x + bm, bc.y + bm, bc.z + bm, bc.w + bm};
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          v[r] = apply_act(acc[i][j][r] * d.alpha + bv[r], d.act, d.act_eps, (d.act_nvalid < 0 ? m < -d.act_nvalid : nb + r < d.act_nvalid));
+        if (d.residual) {
+          const float4 rr = *(const float4*)(d.residual + o);
+          v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+        }
+        if (d.c_dtype == RF_F32) {
+          *(float4*)((float*)d.C + o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          uint2 w;
+          w.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+          w.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+          *(uint2*)((bf16_t*)d.C + o) = w;
+        }
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wc * 32 + j * 16 + 4 * fq + r;
@@ -662,6 +704,14 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   const bool want_ln = d.ln_out != nullptr;
 
   if (d.ab_dtype == RF_F32) {
+    p.f32_vec = 0;
+    if (d.K % 4 == 0 && d.kc == d.K) {
+      if (d.a_mode == RF_AMODE_PLAIN && d.a_rc <= 0 && d.a_ri % 4 == 0 && ((uintptr_t)d.A % 16) == 0 && d.a_bs[0] % 4 == 0 &&
+          d.a_bs[1] % 4 == 0 && d.a_bs[2] % 4 == 0)
+        p.f32_vec |= 1;
+      if (d.b_rc <= 0 && d.b_ri % 4 == 0 && ((uintptr_t)d.B % 16) == 0 && d.b_bs[0] % 4 == 0 && d.b_bs[1] % 4 == 0 && d.b_bs[2] % 4 == 0)
+        p.f32_vec |= 2;
+    }
     if (want_ln) return RF_EINVAL;  // the fused LayerNorm epilogue exists on the bf16 MFMA path only
     p.tilesM = (d.M + 63) / 64;
     p.tilesN = (d.N + 63) / 64;
