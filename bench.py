@@ -9,7 +9,7 @@ d_msa=384, d_pair=288, 8 two-track + 4 three-track + final block, 4 encoder laye
 inputs already resident in HBM, random-init weights.  Independent MSAs shard across ranks (one process
 per GPU); the only collective is the gather of the results to rank 0 (RCCL), inside the timed region.
 Rank 0 prints ONE JSON line.  Extra legs on rank 0 at N=1:
-  * roofline: the dominant kernel (the bf16 MFMA GEMM engine, 128x128 tile family) timed live with HIP events
+  * roofline: the dominant kernel family (the persistent bf16 MFMA GEMM of csrc/gemm_fast.hip) timed live with HIP events
     around every launch of one extra profiled step; achieved = algorithmic FLOPs of those launches / their time.
   * cpu_baseline: the CPU oracle (oracle/rf_oracle.py, a restatement pinned to the reference's golden vectors)
     timed on the host cores on one block of each kind at config-2 shapes (B=1), scaled by the block counts.
@@ -63,7 +63,12 @@ def profile_gemms(model, inputs):
         k_eff = d.K // 9 if d.a_mode == 1 else d.K  # conv: the image is read once algorithmically
         nbytes = nb * (d.M * k_eff * esz + d.N * d.K * esz + d.M * d.N * (4 if d.c_dtype == 0 else 2)
                        + (d.M * d.N * 4 if d.residual else 0))
-        recs.append((s, e, 2.0 * d.M * d.N * d.K * nb, d.ab_dtype, d.M, d.N, d.K, nb, d.a_mode, nbytes))
+        # same predicate as rf_gemm_fast_try (csrc/gemm_fast.hip): plain row-major panels go to the persistent kernel
+        fast = (d.ab_dtype == 1 and d.a_mode == 0 and nb == 1 and d.a_rc <= 0 and d.b_rc <= 0 and d.c_rc <= 0 and d.c_cc <= 0
+                and d.M % 256 == 0 and d.M >= 16384 and d.K >= 64 and d.alpha == 1.0 and d.tile_cfg == 0
+                and (d.N % 256 == 0 or d.N % 288 == 0 or d.N % 192 == 0 or d.N % 128 == 0) and d.bias_mode != 2 and d.act in (0, 1)
+                and not d.ln_out and (d.kc <= 0 or d.kc == d.K))
+        recs.append((s, e, 2.0 * d.M * d.N * d.K * nb, d.ab_dtype, d.M, d.N, d.K, nb, d.a_mode, nbytes, fast))
         return rc
 
     ops.lib.rf_gemm = wrapped
@@ -74,7 +79,7 @@ def profile_gemms(model, inputs):
         ops.lib.rf_gemm = orig
     if os.environ.get("RF_GEMM_TABLE"):
         tab = {}
-        for s, e, fl, dt, M, N, K, nb, amode, _ in recs:
+        for s, e, fl, dt, M, N, K, nb, amode, _, _f in recs:
             t = tab.setdefault((dt, amode, M, N, K, nb), [0.0, 0.0, 0])
             t[0] += s.elapsed_time(e)
             t[1] += fl
@@ -82,11 +87,13 @@ def profile_gemms(model, inputs):
         for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])[:40]:
             log("gemm dt=%d conv=%d M=%d N=%d K=%d batch=%d : %d calls %.2f ms total, %.0f TF/s" % (*k, v[2], v[0], v[1] / v[0] / 1e9))
     fams = {}
-    for s, e, fl, dt, M, N, K, nb, amode, nbytes in recs:
+    for s, e, fl, dt, M, N, K, nb, amode, nbytes, fast in recs:
         if dt != 1:
-            fam = "gemm_f32_kernel (fp32 tiles)"
+            fam = "gemm_f32_kernel (fp32 MFMA 16x16x4)"
         elif amode == 1:
             fam = "gemm_bf16_kernel<conv3x3> (MFMA 16x16x32)"
+        elif fast:
+            fam = "gemm_fast_kernel (persistent, MFMA 16x16x32)"
         else:
             fam = "gemm_bf16_kernel (MFMA 16x16x32)"
         f = fams.setdefault(fam, [0.0, 0.0, 0, 0.0])
@@ -238,7 +245,7 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as fh:
                     pm = json.load(fh)["families"]
-                key = "gemm_bf16_kernel<conv3x3>" if "conv3x3" in name else "gemm_bf16_kernel"
+                key = name.split(" ")[0]
                 traffic = pm[key]["hbm_bytes_per_launch"]
             except (OSError, KeyError, ValueError):
                 pass
