@@ -734,9 +734,24 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   if (!al8(d.b_ri) || !al8(d.b_ro) || !al8(d.b_ko) || !al8(d.b_bs[0]) || !al8(d.b_bs[1]) || !al8(d.b_bs[2]))
     return RF_EALIGN;
 
+  if (want_ln) {
+    // "residual add + LayerNorm of the next sub-layer": fused into the persistent kernel's epilogue for the 288-wide pair
+    // rows (one tile = whole rows); otherwise the normalisation runs as a second launch over the fp32 rows just written
+    if (d.c_dtype != RF_F32 || d.c_rc > 0 || d.c_cc > 0 || batch != 1 || !d.ln_gamma || !d.ln_beta ||
+        ((uintptr_t)d.ln_out % 8) || ((uintptr_t)d.ln_gamma % 16) || ((uintptr_t)d.ln_beta % 16))
+      return RF_EINVAL;
+  }
   if (d.tile_cfg == 0 && !p.dbg && !p.stamps) {  // (stamps of the generic kernel: keep it on the generic kernel)
     int rc = 0;
     if (rf_gemm_fast_try(d, batch, &rc, stream)) return rc;
+    if (want_ln) {
+      rf_gemm_desc d2 = d;
+      d2.ln_out = nullptr;
+      if (rf_gemm_fast_try(d2, batch, &rc, stream)) {
+        if (rc != 0) return rc;
+        return rf_layernorm(d.C, RF_F32, d.c_ri, d.ln_out, RF_BF16, d.N, d.M, d.N, d.ln_gamma, d.ln_beta, d.ln_eps, 1, RF_ACT_NONE, stream);
+      }
+    }
   }
   TileCfg t;
   if (d.tile_cfg > 0 && d.tile_cfg < kNumTiles) {
@@ -754,13 +769,6 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
       t.bn = pick_bn(d.N);
       t.bm = d.M > 64 && ((d.M + 127) / 128) * 128 <= ((d.M + 63) / 64) * 64 + 32 ? 128 : 64;
     }
-  }
-  if (want_ln) {
-    // "residual add + LayerNorm of the next sub-layer": the normalisation runs as a second launch over the fp32 rows
-    // the GEMM has just written (an in-epilogue form was built and measured slower than GEMM + the vectorised row kernel)
-    if (d.c_dtype != RF_F32 || d.c_rc > 0 || d.c_cc > 0 || batch != 1 || !d.ln_gamma || !d.ln_beta ||
-        ((uintptr_t)d.ln_out % 8) || ((uintptr_t)d.ln_gamma % 16) || ((uintptr_t)d.ln_beta % 16))
-      return RF_EINVAL;
   }
   p.tilesM = (d.M + t.bm - 1) / t.bm;
   p.tilesN = (d.N + t.bn - 1) / t.bn;

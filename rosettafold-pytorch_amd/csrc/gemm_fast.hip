@@ -30,6 +30,11 @@ struct FastP {
   int relu;
   int tilesN, ntiles;
   int nt_store;
+  // fused "LayerNorm of the next sub-layer" (LN variant: N == BN, fp32 C with residual): bf16 [M, N] normalised rows
+  void* ln_out;
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
   unsigned long long* stamps;  // timing experiments (tools/gemm_stamps.py): 8 x u64 per workgroup, else null
 };
 
@@ -38,8 +43,9 @@ __device__ __forceinline__ void fast_glds16(const void* src, void* lds_wave_base
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BN, bool OUT_F32, bool HAS_RES, bool STAMP = false>
+template <int BN, bool OUT_F32, bool HAS_RES, bool STAMP = false, bool LN = false>
 __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
+  static_assert(!LN || (OUT_F32 && HAS_RES), "the fused LayerNorm epilogue normalises the updated fp32 residual rows");
   constexpr int BM = 256, BK = 64, NW = 8, TM = 64, TN = BN / 2, WM = TM / 16, WN = TN / 16;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int B_INSTR = BN / 8;                  // wave-level DMA instructions per B tile (8 rows x 128 B each)
@@ -106,6 +112,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
     goff[t] = r * p.ldc + c * EPC;
   }
   const float lo = p.relu ? 0.f : -INFINITY;
+  constexpr int GB_OFF = 2 * STAGE_BYTES;  // LN variant: gamma | beta (BN floats each) behind the stage buffers
+  if constexpr (LN) {
+    for (int i = tid; i < 2 * BN; i += 512) ((float*)(smem + GB_OFF))[i] = i < BN ? p.ln_gamma[i] : p.ln_beta[i - BN];
+  }
 
   // ---- persistent tile walk ----------------------------------------------------------------------------------
   // slot: XCD-aware position of this workgroup inside a round of gridDim.x tiles (workgroups b and b+8 share an XCD
@@ -182,8 +192,56 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
 
     // ---- epilogue: strips overlay the buffer of the last K step (buf ^ 1 now); buf holds the next tile's step 0 ----
     __syncthreads();  // every wave is done reading that buffer
+    float ln_mean[WM], ln_rstd[WM];
+    if constexpr (LN) {
+      // The tile spans whole rows (N == BN): add the residual in the MFMA layout, reduce each row over the lane quads
+      // and the two wave columns (LDS), two-pass variance like the stand-alone kernel.  The strips below then carry the
+      // finished fp32 rows to C and, in a second sweep, the normalised bf16 rows to ln_out: the separate LayerNorm
+      // launch and its 302 MB re-read of the stream disappear.
+      float* const st1 = (float*)(smem + (buf ^ 1) * STAGE_BYTES + 56 * 1024);  // [256 rows][2 wave columns]
+      float* const st2 = st1 + 512;
+      const float* Rl = p.residual + (int64_t)(m0 + wm * TM + fr) * p.ldc + n0 + wn * TN + 4 * fq;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const f32x4 r4 = *(const f32x4*)(Rl + (int64_t)i * 16 * p.ldc + j * 16);
+          acc[i][j] += r4;
+          sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+        }
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        if (fq == 0) st1[(wm * TM + i * 16 + fr) * 2 + wn] = sm;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int row = wm * TM + i * 16 + fr;
+        ln_mean[i] = (st1[row * 2] + st1[row * 2 + 1]) * (1.0f / BN);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dlt = acc[i][j][e] - ln_mean[i];
+            q += dlt * dlt;
+          }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        if (fq == 0) st2[row * 2 + wn] = q;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int row = wm * TM + i * 16 + fr;
+        ln_rstd[i] = rsqrtf((st2[row * 2] + st2[row * 2 + 1]) * (1.0f / BN) + p.ln_eps);
+      }
+    }
     {
-      char* const strip = smem + (buf ^ 1) * STAGE_BYTES + wave * (RP * PITCHW);
+      // (LN variant: both sweeps use the same per-wave stride, so a wave's bf16 strip never overlaps a neighbour's fp32 one)
+      constexpr int WSTRIDE = LN ? (RP * PITCHW > 16 * (TN * 2 + 16) ? RP * PITCHW : 16 * (TN * 2 + 16)) : RP * PITCHW;
+      char* const strip = smem + (buf ^ 1) * STAGE_BYTES + wave * WSTRIDE;
       char* const Cw = (char*)p.C + ((int64_t)(m0 + wm * TM) * p.ldc + n0 + wn * TN) * ESZ;
       const char* const Rw = HAS_RES ? (const char*)p.residual + ((int64_t)(m0 + wm * TM) * p.ldc + n0 + wn * TN) * 4 : nullptr;
 #pragma unroll
@@ -222,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
           f32x4 res[G], vv[G];
 #pragma unroll
           for (int g = 0; g < G; ++g) {
-            if constexpr (HAS_RES) {
+            if constexpr (HAS_RES && !LN) {
               res[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
               if (t0 + g < NIT && (NCH % 64 == 0 || lane + 64 * (t0 + g) < NCH)) res[g] = *(const f32x4*)(Rp + (unsigned)goff[t0 + g] * 4u);
             }
@@ -234,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
           for (int g = 0; g < G; ++g) {
             if (t0 + g >= NIT || !(NCH % 64 == 0 || lane + 64 * (t0 + g) < NCH)) continue;
             f32x4 v = vv[g];
-            if constexpr (HAS_RES) v += res[g];
+            if constexpr (HAS_RES && !LN) v += res[g];
             f32x4* dst = (f32x4*)(Cp + (unsigned)goff[t0 + g] * (unsigned)ESZ);
             if (p.nt_store)
               __builtin_nontemporal_store(v, dst);
@@ -242,6 +300,41 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
               *dst = v;
           }
         }
+      }
+    }
+    if constexpr (LN) {
+      constexpr int PITCHB = TN * 2 + 16, CPRB = TN * 2 / 16, NCHB = 16 * CPRB, NITB = (NCHB + 63) / 64;
+      static_assert(8 * (RP * PITCHW > 16 * PITCHB ? RP * PITCHW : 16 * PITCHB) <= 56 * 1024, "strips overlap the row statistics");
+      constexpr int WSTRIDE = RP * PITCHW > 16 * PITCHB ? RP * PITCHW : 16 * PITCHB;
+      char* const stripb = smem + (buf ^ 1) * STAGE_BYTES + wave * WSTRIDE;
+      const float* const gam = (const float*)(smem + GB_OFF) + wn * TN + 4 * fq;
+      bf16_t* const Lw = (bf16_t*)p.ln_out + (int64_t)(m0 + wm * TM) * BN + wn * TN;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        char* lrow = stripb + fr * PITCHB;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          const f32x4 g4 = *(const f32x4*)(gam + j * 16), b4 = *(const f32x4*)(gam + BN + j * 16);
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (acc[i][j][e] - ln_mean[i]) * ln_rstd[i] * g4[e] + b4[e];
+          uint2 w;
+          w.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+          w.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+          *(uint2*)(lrow + (j * 16 + 4 * fq) * 2) = w;
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < NITB; ++t) {
+          const int idx = lane + 64 * t;
+          if (NCHB % 64 == 0 || idx < NCHB) {
+            const int r = idx / CPRB, c = idx % CPRB;
+            const f32x4 v = *(const f32x4*)(stripb + r * PITCHB + c * 16);
+            *(f32x4*)(Lw + (int64_t)(i * 16 + r) * BN + c * 8) = v;
+          }
+        }
+        asm volatile("" ::: "memory");
       }
     }
     if constexpr (STAMP) {
@@ -261,10 +354,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
   }
 }
 
-template <int BN, bool OUT_F32, bool HAS_RES, bool STAMP = false>
+template <int BN, bool OUT_F32, bool HAS_RES, bool STAMP = false, bool LN = false>
 static int launch_fast(const FastP& p, hipStream_t s) {
   constexpr int STAGE = (256 + BN) * 64 * 2;
-  auto k = gemm_fast_kernel<BN, OUT_F32, HAS_RES, STAMP>;
+  auto k = gemm_fast_kernel<BN, OUT_F32, HAS_RES, STAMP, LN>;
   static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
   (void)once;
   static int n_cu = 0;
@@ -275,7 +368,7 @@ static int launch_fast(const FastP& p, hipStream_t s) {
     n_cu = prop.multiProcessorCount;
   }
   const int grid = p.ntiles < n_cu ? p.ntiles : n_cu;
-  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), 2 * STAGE, s, p);
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), 2 * STAGE + (LN ? 2 * BN * 4 : 0), s, p);
   return rf_launch_status();
 }
 
@@ -290,7 +383,12 @@ int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
   if (d.ab_dtype != RF_BF16 || d.a_mode != RF_AMODE_PLAIN || batch != 1) return 0;
   if (d.a_rc > 0 || d.b_rc > 0 || d.c_rc > 0 || d.c_cc > 0 || d.kc != d.K) return 0;
   if (d.M % 256 != 0 || d.M < 16384 || d.K < 64 || d.K % 8 != 0 || d.alpha != 1.0f) return 0;
-  if (d.bias_mode == RF_BIAS_ROW || (d.act != RF_ACT_NONE && d.act != RF_ACT_RELU) || d.ln_out) return 0;
+  if (d.bias_mode == RF_BIAS_ROW || (d.act != RF_ACT_NONE && d.act != RF_ACT_RELU)) return 0;
+  // fused next-LayerNorm epilogue: the 288-wide pair rows (one tile spans whole rows), fp32 C with residual, no activation
+  const bool ln = d.ln_out != nullptr;
+  if (ln && (d.N != 288 || d.c_dtype != RF_F32 || !d.residual || d.act != RF_ACT_NONE || !d.ln_gamma || !d.ln_beta ||
+             ((uintptr_t)d.ln_out % 16)))
+    return 0;
   if (d.a_ri % 8 || d.b_ri % 8 || d.c_ri % 8 || ((uintptr_t)d.A % 16) || ((uintptr_t)d.B % 16) || ((uintptr_t)d.C % 16)) return 0;
   if (d.bias_mode == RF_BIAS_COL && ((uintptr_t)d.bias % 16)) return 0;
   if (d.residual && (d.c_dtype != RF_F32 || ((uintptr_t)d.residual % 16))) return 0;
@@ -314,6 +412,11 @@ int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
   hipStream_t s = (hipStream_t)stream;
   const bool f32 = d.c_dtype == RF_F32, res = d.residual != nullptr;
   p.stamps = g_fast_stamps;
+  p.ln_out = d.ln_out; p.ln_gamma = d.ln_gamma; p.ln_beta = d.ln_beta; p.ln_eps = d.ln_eps;
+  if (ln) {
+    *rc = launch_fast<288, true, true, false, true>(p, s);
+    return 1;
+  }
   if (p.stamps && bn == 256 && !f32) {  // timing experiment: instrumented twin of the bf16-output 256-wide kernel
     *rc = launch_fast<256, false, false, true>(p, s);
     return 1;

@@ -345,6 +345,9 @@ def favor_attention(qkv, pc, out, x_strides, o_strides, q_off, k_off, v_off, n_b
 # Measured on MI355X (tools/ln_fuse_bench.py): the fused epilogue costs more than residual GEMM + the vectorised
 # rf_layernorm (0.50 vs 0.37 ms at M=262144, N=288, K=512), so it is opt-in.
 FUSE_LN = False
+# fused residual + next-LayerNorm epilogue of the persistent GEMM for the 288-wide pair rows: correct, but measured
+# slower than GEMM + the vectorised LayerNorm launch (444 vs 213 + 95 us per sub-layer), so opt-in
+FUSE_LN_288 = bool(int(__import__("os").environ.get("RF_FUSED_LN", "0")))
 
 
 def linear_residual_ln(x, w, bias, x_res, next_ln):
@@ -352,7 +355,9 @@ def linear_residual_ln(x, w, bias, x_res, next_ln):
     (bf16 operands, full rows per tile), also returns LayerNorm_next(x_res) in bf16; otherwise returns None and the
     caller normalises with rf_layernorm."""
     N = w.shape[0]
-    if FUSE_LN and next_ln is not None and x.dtype == BF16 and N <= 384 and N % 4 == 0 and x_res.is_contiguous():
+    # N == 288 with whole 256-row panels: the persistent GEMM normalises the rows in its epilogue (csrc/gemm_fast.hip)
+    fused = FUSE_LN or (FUSE_LN_288 and N == 288 and (x_res.numel() // N) % 256 == 0 and (x_res.numel() // N) >= 16384)
+    if fused and next_ln is not None and x.dtype == BF16 and N <= 384 and N % 4 == 0 and x_res.is_contiguous():
         xn = torch.empty(x_res.shape, device=x_res.device, dtype=BF16)
         linear(x, w, bias, out=x_res, residual=x_res,
                ln=(xn, next_ln.weight.detach(), next_ln.bias.detach(), next_ln.eps))

@@ -72,6 +72,36 @@ def test_gemm_persistent_exact_integers():
         assert torch.equal(y.float(), x.float() @ w.float().t())
 
 
+@pytest.mark.parametrize("K", [512, 288, 1152])
+def test_gemm_persistent_fused_layernorm(K):
+    """N = 288 residual GEMM over whole 256-row panels: the persistent kernel adds the residual, writes the fp32 rows and
+    emits LayerNorm_next(rows) in bf16 from the same epilogue (no second launch)."""
+    import torch.nn as nn
+    M, N = 32768, 288
+    x, w, b = randn(M, K, dtype=torch.bfloat16), randn(N, K, dtype=torch.bfloat16, seed=1) * 0.1, randn(N, seed=2)
+    res = randn(M, N, seed=3) * 2 + 0.5
+    lnm = nn.LayerNorm(N).to(DEV)
+    with torch.no_grad():
+        lnm.weight.copy_(randn(N, seed=4)); lnm.bias.copy_(randn(N, seed=5))
+    ref = res + x.float() @ w.float().t() + b
+    ref_ln = torch.nn.functional.layer_norm(ref, (N,), lnm.weight, lnm.bias, lnm.eps)
+    out = res.clone()
+    ops.FUSE_LN_288 = True
+    try:
+        xn = ops.linear_residual_ln(x, w, b, out, lnm)
+    finally:
+        ops.FUSE_LN_288 = False
+    assert xn is not None and xn.dtype == torch.bfloat16
+    assert rel_err(out, ref) < 2e-2
+    assert rel_err(xn, ref_ln) < 3e-2
+    # against the two-launch form on the same operands: identical fp32 rows, LayerNorm equal to bf16 rounding
+    out2 = res.clone()
+    ops.linear(x, w, b, out=out2, residual=out2)
+    assert rel_err(out, out2) < 1e-6
+    xn2 = ops.layernorm(out2, lnm.weight.detach(), lnm.bias.detach(), eps=lnm.eps, out_dtype=torch.bfloat16)
+    assert rel_err(xn, xn2) < 1e-2
+
+
 @pytest.mark.parametrize("cfg", list(range(1, 19)))
 def test_gemm_all_tile_configs(cfg):
     M, N, K = 777, 600, 352
