@@ -30,6 +30,7 @@ struct FastP {
   int relu;
   int tilesN, ntiles;
   int nt_store;
+  int no_lag;  // experiment switch: 1 = waves 4-7 run the same phase order as waves 0-3
   // fused "LayerNorm of the next sub-layer" (LN variant: N == BN, fp32 C with residual): bf16 [M, N] normalised rows
   void* ln_out;
   const float* ln_gamma;
@@ -134,6 +135,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
   int buf = 0;
   stage(0, m0, n0, 0);
 
+  auto run = [&](auto lag_tag) {
+  constexpr bool LAG = decltype(lag_tag)::value;
   while (true) {
     const int lid_next = lid + G_;
     const bool has_next = lid_next < p.ntiles;
@@ -148,6 +151,37 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
       for (int i = 0; i < WM; ++i) acc[i][j] = bc;
     }
 
+    // K loop.  The two waves of a SIMD (w and w + 4) would otherwise run the same phases in lockstep: both issue their
+    // fragment reads, then both queue for the matrix pipe, and the older one waits at the K-step barrier for its partner
+    // (22 % of a tile, tools/gemm_stamps.py).  Waves 4-7 therefore LAG by one phase: they carry the second-half fragments
+    // of a K step across the barrier and issue those MFMAs first thing in the next step, while waves 0-3 are reading:
+    //   waves 0-3:  R0 M0 R1 M1 | R0 M0 R1 M1 |        waves 4-7:  M1' R0 M0 R1 | M1' R0 M0 R1 | ... M1'
+    // (one barrier per K step as before; the carried fragments are in registers, and a lagging wave retires its R1 reads
+    // before the barrier, so the buffer can be re-staged right behind it).
+    bf16x8 af[WM], bfr[WN];
+    auto read_frags = [&](int kk) {
+      const char* a_lds = smem + buf * STAGE_BYTES;
+      const char* b_lds = a_lds + A_BYTES;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int row = wm * TM + i * 16 + fr;
+        af[i] = *(const bf16x8*)(a_lds + (row * 8 + ((kk * 4 + fq) ^ ((row >> 1) & 7))) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int row = wn * TN + j * 16 + fr;
+        bfr[j] = *(const bf16x8*)(b_lds + (row * 8 + ((kk * 4 + fq) ^ ((row >> 1) & 7))) * 16);
+      }
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          // weight tile as MFMA-A, activation tile as MFMA-B: lane holds C[m = ..+fr][n = ..+4*fq .. +3]
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    };
+    const bool half_tail = k_tail && (p.K % BK) <= 32;  // K tail of <= 32: the second half of the last step is all zeros
     for (int kt = 0; kt < nk; ++kt) {
       if constexpr (STAMP) tk_x = clock64();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -158,35 +192,29 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
         stage(buf ^ 1, m0, n0, kt + 1);
       else if (has_next)
         stage(buf ^ 1, m0n, n0n, 0);
-      const char* a_lds = smem + buf * STAGE_BYTES;
-      const char* b_lds = a_lds + A_BYTES;
-      const bool half = k_tail && kt == nk - 1 && (p.K % BK) <= 32;  // tail of <= 32: the second MFMA half is all zeros
-#pragma unroll
-      for (int kk = 0; kk < BK / 32; ++kk) {
-        if (kk == 1 && half) break;
-        bf16x8 af[WM], bfr[WN];
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-          const int row = wm * TM + i * 16 + fr;
-          af[i] = *(const bf16x8*)(a_lds + (row * 8 + ((kk * 4 + fq) ^ ((row >> 1) & 7))) * 16);
+      const bool second = !(half_tail && kt == nk - 1);
+      if constexpr (LAG) {
+        if (kt > 0) mfmas();  // M1 of the previous step, from the carried fragments
+        read_frags(0);
+        mfmas();
+        if (second) read_frags(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else {
+        read_frags(0);
+        mfmas();
+        if (second) {
+          read_frags(1);
+          mfmas();
         }
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          const int row = wn * TN + j * 16 + fr;
-          bfr[j] = *(const bf16x8*)(b_lds + (row * 8 + ((kk * 4 + fq) ^ ((row >> 1) & 7))) * 16);
-        }
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int j = 0; j < WN; ++j)
-            // weight tile as MFMA-A, activation tile as MFMA-B: lane holds C[m = ..+fr][n = ..+4*fq .. +3]
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
       buf ^= 1;
       if constexpr (STAMP) {
         asm volatile("s_nop 0" ::: "memory");
         tk_mma += clock64() - tk_x;
       }
+    }
+    if constexpr (LAG) {
+      if (!half_tail) mfmas();  // M1 of the last step
     }
     if constexpr (STAMP) tk_x = clock64();
 
@@ -346,6 +374,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
     m0 = m0n;
     n0 = n0n;
   }
+  };
+  if (wave < 4 || p.no_lag)
+    run(std::false_type{});
+  else
+    run(std::true_type{});
   if constexpr (STAMP) {
     if (tid == 0 && p.stamps) {
       unsigned long long* o = p.stamps + (size_t)blockIdx.x * 8;
@@ -412,6 +445,7 @@ int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
   hipStream_t s = (hipStream_t)stream;
   const bool f32 = d.c_dtype == RF_F32, res = d.residual != nullptr;
   p.stamps = g_fast_stamps;
+  p.no_lag = getenv("RF_GEMM_NO_LAG") != nullptr;
   p.ln_out = d.ln_out; p.ln_gamma = d.ln_gamma; p.ln_beta = d.ln_beta; p.ln_eps = d.ln_eps;
   if (ln) {
     *rc = launch_fast<288, true, true, false, true>(p, s);
