@@ -821,9 +821,10 @@ static int launch_favor(const FavorAttnP& p, hipStream_t s) {
   int ncu = 256;
   const int grid = p.nitems < ncu ? p.nitems : ncu;
   // measured (tools/favor_bench.py): the 8-wave kernel wins for the ReLU features (no AGPR traffic at <= 256
-  // registers); the softmax-feature variant spills there, so it stays on the 4-wave kernel.  RF_FAVOR4 / RF_FAVOR8 force one.
+  // registers) and for the softmax features up to 128-row sequences (674 vs 720 us on the MSA-column shape; 9 spilled
+  // registers); at 256 rows the softmax variant spills 59 and stays on the 4-wave kernel.  RF_FAVOR4 / RF_FAVOR8 force one.
   static const bool force4 = getenv("RF_FAVOR4") != nullptr, force8 = getenv("RF_FAVOR8") != nullptr;
-  const bool use4 = force4 || (SM && !force8);
+  const bool use4 = force4 || (SM && LS > 128 && !force8);
   if (use4) {
     auto k = favor_attention_kernel<LS, SM>;
     static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
