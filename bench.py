@@ -34,6 +34,10 @@ CONFIGS = {
     2: dict(B=4, N=128, L=256, model=dict(d_msa=384, d_pair=288, d_node=32, d_edge=32, d_state=32,
                                           n_two_track_blocks=8, n_three_track_blocks=5, n_encoder_layers=4,
                                           max_len=260, n_neighbors=[128, 128, 64, 64, 64])),
+    # configs[3]: long-sequence stress (not the metric's configuration; `--config 4` for a manual run)
+    4: dict(B=1, N=64, L=1024, model=dict(d_msa=384, d_pair=288, d_node=32, d_edge=32, d_state=32,
+                                          n_two_track_blocks=8, n_three_track_blocks=5, n_encoder_layers=4,
+                                          max_len=1030, n_neighbors=[128, 128, 64, 64, 64])),
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -228,7 +232,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "residues/sec forward (L=256, N=128)", "value": world * B * L * args.steps / dt,
+            "metric": f"residues/sec forward (L={L}, N={N})", "value": world * B * L * args.steps / dt,
             "unit": "residues/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
