@@ -109,6 +109,14 @@ int rf_softmax(const float* x, int64_t x_rs, int64_t x_cs, void* y, int y_dtype,
 int rf_tied_softmax(const float* logits, void* att, int att_dtype, float* att_sym, int64_t sym_ld, int B, int H,
                     int L, void* stream);
 
+/* Tied MSA-row attention, logits + softmax in one launch (rf.py:252-255,261-265), bf16 only:
+ *   att[b,h,i,:] = softmax_j( sum_{n,d} q[b,n,i,h,d] * k[b,n,j,h,d] )   -> att bf16 [B,H,L,L]
+ * q / k element (b,n,l,h,d) at b*b_stride + n*n_stride + l*l_stride + h*d_head + d (q already scaled, rf.py:252);
+ * d_head == 32 and L in {64,128,192,256} (RF_EINVAL otherwise: use rf_gemm + rf_tied_softmax).  att_sym as in
+ * rf_tied_softmax (may be NULL). */
+int rf_tied_logits_softmax(const void* q, const void* k, int64_t b_stride, int64_t n_stride, int64_t l_stride, void* att,
+                           float* att_sym, int64_t sym_ld, int B, int H, int N, int L, int d_head, void* stream);
+
 /* PositionWiseWeightFactor core (rf.py:205-217): w[b,n,h,l] = softmax_n( scale * sum_{c<dlen} q0[b,l,h,c]*k[b,n,l,h,c] ).
  * q0: [B,L,H*dlen] (dtype q0_dtype, ld q0_ld); k: T rows [B,N,L,*] of ld k_ld, head h at column k_col0 + h*k_hstride.
  *   - direct form:    q0 = to_q(row 0), k = to_k(x), dlen = k_hstride = d_head;

@@ -44,6 +44,7 @@ PROTOTYPES = {
     "rf_sym_layernorm": [vp, vp, i32, i32, i32, i32, f32, vp],
     "rf_softmax": [vp, i64, i64, vp, i32, i64, i64, i32, f32, vp],
     "rf_tied_softmax": [vp, vp, i32, vp, i64, i32, i32, i32, vp],
+    "rf_tied_logits_softmax": [vp, vp, i64, i64, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp],
     "rf_poswise": [vp, i32, i64, vp, i64, i32, i32, i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp],
     "rf_weighted_msa_sum": [vp, i32, vp, vp, i64, i32, i32, i32, i32, vp],
     "rf_instnorm_stats": [vp, i32, vp, i32, i64, i32, vp],

@@ -34,6 +34,7 @@ VT_ROWS = 80   # 64 value rows + the ones row (k' sums) padded to a multiple of 
 class _Runtime:
     dtype = torch.bfloat16
     fused_favor = True  # use the fused FAVOR+ kernel when the shape allows (bf16, dim_head 64, seq 128/256)
+    fused_tied = not bool(int(__import__("os").environ.get("RF_NO_FUSED_TIED", "0")))  # tied-attention logits + softmax in one launch
     head_major_qkv = bool(int(__import__("os").environ.get("RF_HEAD_MAJOR_QKV", "0")))
     # Producer -> consumer chains whose intermediate (q|k|v, feed-forward hidden) is larger than this many bytes are run
     # panel by panel, so the intermediate panel is still in the 256 MB Infinity Cache when its consumer reads it
@@ -319,16 +320,20 @@ class SoftTiedAttentionOverResidues(RFModule):
         v_t = torch.empty(B, N, D, Lr, device=dev, dtype=T())
         ops.gemm(self.wt("v", self.to_v), xn, v_t, D, Lr, D, batch=(B * N, 1, 1), b_bs=(Lr * D, 0, 0),
                  c_bs=(D * Lr, 0, 0), c_row=(0, 0, Lr), bias=_f(self.to_v.bias), bias_mode=L.BIAS_ROW)
-        # logits[b,h,i,j] = sum_{n,d} q k   (contraction over N*dh, rf.py:254)
-        logits = torch.empty(B, H, Lr, Lr, device=dev, dtype=F32)
+        # logits[b,h,i,j] = sum_{n,d} q k   (contraction over N*dh, rf.py:254), softmax over j (rf.py:255)
         W3 = 3 * D
-        ops.gemm(qkp, qkp, logits, Lr, Lr, N * dh, batch=(B, H, 1), b_off=D,
-                 a_bs=(N * Lr * W3, dh, 0), a_row=(0, 0, W3), a_ko=Lr * W3,
-                 b_bs=(N * Lr * W3, dh, 0), b_row=(0, 0, W3), b_ko=Lr * W3, kc=dh,
-                 c_bs=(H * Lr * Lr, Lr * Lr, 0), c_row=(0, 0, Lr))
         att = torch.empty(B, H, Lr, Lr, device=dev, dtype=T())
         att_sym = torch.empty(B, Lr, Lr, H, device=dev, dtype=F32) if want_att else None
-        ops.tied_softmax(logits, att, att_sym, H)
+        if RT.fused_tied and T() == torch.bfloat16 and dh == 32 and Lr in (64, 128, 192, 256):
+            # one launch: 6-8-stage DMA ring over the N steps, logits in registers, wave-local softmax (csrc/tied.hip)
+            ops.tied_logits_softmax(qkp, qkp[..., D:], N * Lr * W3, Lr * W3, W3, att, att_sym, B, H, N, Lr, dh)
+        else:
+            logits = torch.empty(B, H, Lr, Lr, device=dev, dtype=F32)
+            ops.gemm(qkp, qkp, logits, Lr, Lr, N * dh, batch=(B, H, 1), b_off=D,
+                     a_bs=(N * Lr * W3, dh, 0), a_row=(0, 0, W3), a_ko=Lr * W3,
+                     b_bs=(N * Lr * W3, dh, 0), b_row=(0, 0, W3), b_ko=Lr * W3, kc=dh,
+                     c_bs=(H * Lr * Lr, Lr * Lr, 0), c_row=(0, 0, Lr))
+            ops.tied_softmax(logits, att, att_sym, H)
         # out[b,n,i,(h,d)] = sum_j att[b,h,i,j] v[b,n,h,j,d]   (rf.py:257-258)
         out = torch.empty(B, N, Lr, D, device=dev, dtype=T())
         ops.gemm(att, v_t, out, Lr, N * dh, Lr, batch=(B, H, 1),

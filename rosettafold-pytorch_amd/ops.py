@@ -132,6 +132,15 @@ def softmax(x, x_off, x_rs, x_cs, y, y_off, y_rs, rows, cols, scale=1.0):
           "rf_softmax")
 
 
+def tied_logits_softmax(q, k, b_stride, n_stride, l_stride, att, att_sym, B, H, N, L_, d_head):
+    """att[b,h,i,:] = softmax_j(sum_{n,d} q k) in one launch (csrc/tied.hip); q, k: bf16 views into the projection output."""
+    _need_cuda(q, k, att, att_sym)
+    check(lib.rf_tied_logits_softmax(ptr(q), ptr(k), b_stride, n_stride, l_stride, ptr(att), ptr(att_sym),
+                                     att_sym.shape[-1] if att_sym is not None else 0, B, H, N, L_, d_head, stream()),
+          "rf_tied_logits_softmax")
+    return att
+
+
 def tied_softmax(logits, att, att_sym=None, sym_ld=0):
     B, H, L_, _ = logits.shape
     _need_cuda(logits, att, att_sym)

@@ -241,6 +241,26 @@ def test_layernorm_narrow_rows(D, odt, rows):
         assert rel_err(y, ref) < 1e-5
 
 
+@pytest.mark.parametrize("B,H,N,Lr", [(1, 2, 5, 64), (2, 3, 37, 128), (1, 12, 16, 192), (2, 12, 128, 256)])
+def test_tied_logits_softmax(B, H, N, Lr):
+    """One-launch tied-attention logits + softmax (csrc/tied.hip) against the einsum/softmax formula (rf.py:254-265) on
+    the same bf16 operands laid out as the q|k|p projection output [B,N,L,3D]."""
+    dh = 32
+    D = H * dh
+    qkp = (randn(B, N, Lr, 3 * D) * (0.6 / math.sqrt(N))).bfloat16()
+    q = qkp[..., :D].float().view(B, N, Lr, H, dh)
+    k = qkp[..., D:2 * D].float().view(B, N, Lr, H, dh)
+    ref = torch.einsum("bnihd,bnjhd->bhij", q, k).softmax(-1)
+    att = torch.empty(B, H, Lr, Lr, device=DEV, dtype=torch.bfloat16)
+    sym = torch.empty(B, Lr, Lr, H, device=DEV, dtype=torch.float32)
+    ops.tied_logits_softmax(qkp, qkp[..., D:], N * Lr * 3 * D, Lr * 3 * D, 3 * D, att, sym, B, H, N, Lr, dh)
+    assert rel_err(att, ref) < 1.5e-2
+    assert (att.float().sum(-1) - 1).abs().max() < 2e-2
+    a = att.float()
+    assert rel_err(sym, (0.5 * (a + a.transpose(-1, -2))).permute(0, 2, 3, 1)) < 1e-6
+    assert torch.equal(sym, sym.transpose(1, 2))  # reference tests/test_module.py:406-413
+
+
 def test_softmax_and_tied():
     B, H, Lr = 2, 3, 50
     lg = randn(B, H, Lr, Lr) * 4
