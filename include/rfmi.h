@@ -33,6 +33,10 @@ extern "C" {
 #define RF_ACT_ELU 2
 #define RF_ACT_RELU_EPS 3 /* relu(x)+eps for column < act_nvalid (row < -act_nvalid if negative), 0 beyond (FAVOR+ ReLU features) */
 #define RF_ACT_LEAKY 4    /* LeakyReLU(0.01), rf_layernorm only */
+#define RF_ACT_BLOCK_LN32 5 /* rf_gemm, bf16 path, 256x256 tiles: LayerNorm over every aligned 32x32 block of the output
+                            * (block (i,j) = rows 32i.., cols 32j..; feature k = 32*(row%32) + col%32) with affine
+                            * ln_gamma/ln_beta[1024], ln_eps; ln_out must be NULL.  The outer-product features of
+                            * OuterProductMean normalised in the GEMM epilogue (rf.py:416,424-426). */
 
 #define RF_BIAS_NONE 0
 #define RF_BIAS_COL 1 /* bias[n] */

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librfmi.so")
 
 RF_F32, RF_BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_ELU, ACT_RELU_EPS, ACT_LEAKY = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_ELU, ACT_RELU_EPS, ACT_LEAKY, ACT_BLOCK_LN32 = 0, 1, 2, 3, 4, 5
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 AMODE_PLAIN, AMODE_CONV3X3 = 0, 1
 

@@ -283,9 +283,53 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_bf16_kernel(const Gemm
   // ---- epilogue: lane holds C[m][n..n+3], m = ..+fr, n = ..+4*fq; the bias is already inside the accumulators ----
   if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
   const int64_t c_z = z0 * d.c_bs[0] + z1 * d.c_bs[1] + z2 * d.c_bs[2];
-  const bool simple = d.act == RF_ACT_NONE || d.act == RF_ACT_RELU;  // branch-free form max(acc * alpha, lo)
+  const bool simple = d.act == RF_ACT_NONE || d.act == RF_ACT_RELU || d.act == RF_ACT_BLOCK_LN32;  // branch-free form max(acc * alpha, lo)
   const float lo = d.act == RF_ACT_RELU ? 0.f : -INFINITY;
   const float alpha = d.alpha;
+  if constexpr (BM == 256 && BN == 256 && WGM == 4 && WGN == 2 && AMODE == RF_AMODE_PLAIN) {
+    if (d.act == RF_ACT_BLOCK_LN32) {
+      // LayerNorm over each aligned 32x32 output block (the 1024 outer-product features of one residue pair): a wave's
+      // 64 x 128 block holds 2 x 4 of them, each spread over all 64 lanes (2 x 2 MFMA tiles x 4 registers): statistics
+      // are two wave reductions per block, two-pass like the stand-alone kernel.  Feature k = 32 * (row % 32) + col % 32.
+#pragma unroll
+      for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+        for (int pj = 0; pj < 4; ++pj) {
+          float sm = 0.f;
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              const f32x4 v = acc[2 * pi + a][2 * pj + b];
+              sm += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+          const float mean = wave_sum(sm) * (1.0f / 1024.0f);
+          float q = 0.f;
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float dl = acc[2 * pi + a][2 * pj + b][e] - mean;
+                q += dl * dl;
+              }
+          const float rstd = rsqrtf(wave_sum(q) * (1.0f / 1024.0f) + d.ln_eps);
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+              const int k = (a * 16 + fr) * 32 + b * 16 + 4 * fq;
+              const float4 g4 = *(const float4*)(d.ln_gamma + k), b4 = *(const float4*)(d.ln_beta + k);
+              f32x4& v = acc[2 * pi + a][2 * pj + b];
+              v[0] = (v[0] - mean) * rstd * g4.x + b4.x;
+              v[1] = (v[1] - mean) * rstd * g4.y + b4.y;
+              v[2] = (v[2] - mean) * rstd * g4.z + b4.z;
+              v[3] = (v[3] - mean) * rstd * g4.w + b4.w;
+            }
+        }
+    }
+  }
   {
     // Wave-private staged epilogue.  The 8-byte-per-lane stores of the MFMA layout are store-issue bound, so each
     // wave converts its own TM x TN accumulator block 16 (or 32) rows at a time into a private LDS strip and reads it
@@ -704,6 +748,7 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   const bool want_ln = d.ln_out != nullptr;
 
   if (d.ab_dtype == RF_F32) {
+    if (d.act == RF_ACT_BLOCK_LN32) return RF_EINVAL;  // bf16 MFMA path only
     p.f32_vec = 0;
     if (d.K % 4 == 0 && d.kc == d.K) {
       if (d.a_mode == RF_AMODE_PLAIN && d.a_rc <= 0 && d.a_ri % 4 == 0 && ((uintptr_t)d.A % 16) == 0 && d.a_bs[0] % 4 == 0 &&
@@ -769,6 +814,12 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
       t.bn = pick_bn(d.N);
       t.bm = d.M > 64 && ((d.M + 127) / 128) * 128 <= ((d.M + 63) / 64) * 64 + 32 ? 128 : 64;
     }
+  }
+  if (d.act == RF_ACT_BLOCK_LN32) {
+    if (d.a_mode != RF_AMODE_PLAIN || d.M % 256 || d.N % 256 || d.K < 64 || !d.ln_gamma || !d.ln_beta || d.ln_out ||
+        d.bias_mode != RF_BIAS_NONE || d.alpha != 1.0f || ((uintptr_t)d.ln_gamma % 16) || ((uintptr_t)d.ln_beta % 16))
+      return RF_EINVAL;
+    t.bm = 256; t.bn = 256; t.bk = 64;
   }
   p.tilesM = (d.M + t.bm - 1) / t.bm;
   p.tilesN = (d.N + t.bn - 1) / t.bn;

@@ -34,6 +34,7 @@ VT_ROWS = 80   # 64 value rows + the ones row (k' sums) padded to a multiple of 
 class _Runtime:
     dtype = torch.bfloat16
     fused_favor = True  # use the fused FAVOR+ kernel when the shape allows (bf16, dim_head 64, seq 128/256)
+    fused_outer_ln = not bool(int(__import__("os").environ.get("RF_NO_FUSED_OUTER_LN", "0")))  # LayerNorm(1024) in the outer-product GEMM epilogue
     fused_tied = not bool(int(__import__("os").environ.get("RF_NO_FUSED_TIED", "0")))  # tied-attention logits + softmax in one launch
     head_major_qkv = bool(int(__import__("os").environ.get("RF_HEAD_MAJOR_QKV", "0")))
     # Producer -> consumer chains whose intermediate (q|k|v, feed-forward hidden) is larger than this many bytes are run
@@ -593,9 +594,18 @@ class OuterProductMean(RFModule):
         B, Lr, P, _ = x_t.shape
         PP = P * P
         co = torch.empty(B, Lr, Lr, PP, device=x_t.device, dtype=T())
-        ops.gemm(x_t, y_t, co, Lr * P, Lr * P, N, batch=(B, 1, 1), a_bs=(Lr * P * N, 0, 0), b_bs=(Lr * P * N, 0, 0),
-                 c_bs=(Lr * Lr * PP, 0, 0), c_row=(P, Lr * PP, P), c_col=(P, PP))
-        cn = ln(self.to_out[0], co)
+        lnm = self.to_out[0]
+        if T() == torch.bfloat16 and P == 32 and (Lr * P) % 256 == 0 and N >= 64 and RT.fused_outer_ln:
+            # LayerNorm(1024) of every pair's outer-product block inside the GEMM epilogue (fp32 statistics on the
+            # accumulators): the separate pass over the 0.5 GB feature tensor disappears
+            ops.gemm(x_t, y_t, co, Lr * P, Lr * P, N, batch=(B, 1, 1), a_bs=(Lr * P * N, 0, 0), b_bs=(Lr * P * N, 0, 0),
+                     c_bs=(Lr * Lr * PP, 0, 0), c_row=(P, Lr * PP, P), c_col=(P, PP), act=L.ACT_BLOCK_LN32,
+                     block_ln=(_f(lnm.weight), _f(lnm.bias), lnm.eps))
+            cn = co
+        else:
+            ops.gemm(x_t, y_t, co, Lr * P, Lr * P, N, batch=(B, 1, 1), a_bs=(Lr * P * N, 0, 0), b_bs=(Lr * P * N, 0, 0),
+                     c_bs=(Lr * Lr * PP, 0, 0), c_row=(P, Lr * PP, P), c_col=(P, PP))
+            cn = ln(lnm, co)
         return ops.linear(cn, self.wt("w", self.to_out[1]), _f(self.to_out[1].bias), out_dtype=F32)
 
     def forward(self, x, y=None):

@@ -47,7 +47,7 @@ def gemm(A, B, Cout, M, N, K, *, batch=(1, 1, 1), a_off=0, b_off=0, c_off=0,
          b_bs=(0, 0, 0), b_row=(0, 0, None), b_ko=0, kc=0,
          c_bs=(0, 0, 0), c_row=(0, 0, None), c_col=(0, 0),
          bias=None, bias_mode=None, act=L.ACT_NONE, act_nvalid=0, act_eps=0.0, alpha=1.0,
-         residual=None, res_off=None, conv=None, tile_cfg=0, ln=None):
+         residual=None, res_off=None, conv=None, tile_cfg=0, ln=None, block_ln=None):
     """C = epilogue(alpha * A @ B^T) with the strided/batched/chunked addressing of rf_gemm_desc.
     *_row = (rc, ro, ri): offset(m) = (m // rc)*ro + (m % rc)*ri, rc=0 -> m*ri.  ri=None -> K (A,B) / N (C).
     c_col = (cc, co).  Offsets are in elements.  conv = (n, h, w, c, dilation) selects implicit 3x3 im2col."""
@@ -83,6 +83,10 @@ def gemm(A, B, Cout, M, N, K, *, batch=(1, 1, 1), a_off=0, b_off=0, c_off=0,
         if residual.dtype != F32:
             raise TypeError("residual must be fp32")
         d.residual = residual.data_ptr() + (c_off if res_off is None else res_off) * 4
+    if block_ln is not None:  # (gamma[1024], beta[1024], eps) with act=ACT_BLOCK_LN32: LayerNorm over 32x32 output blocks
+        g, b, eps = block_ln
+        _need_cuda(g, b)
+        d.ln_gamma, d.ln_beta, d.ln_eps = g.data_ptr(), b.data_ptr(), float(eps)
     if ln is not None:  # (out bf16 [M,N], gamma, beta, eps): fused LayerNorm of the result rows
         ln_out, g, b, eps = ln
         _need_cuda(ln_out, g, b)

@@ -261,6 +261,21 @@ def test_tied_logits_softmax(B, H, N, Lr):
     assert torch.equal(sym, sym.transpose(1, 2))  # reference tests/test_module.py:406-413
 
 
+def test_gemm_block_layernorm_epilogue():
+    """Outer-product GEMM with LayerNorm(1024) of every 32x32 output block in the epilogue (OuterProductMean, rf.py:416,
+    424-426) against einsum + layer_norm; operands / output laid out exactly as the model's call."""
+    B, Lr, P, N = 2, 24, 32, 72
+    PP = P * P
+    x_t, y_t = randn(B, Lr, P, N, dtype=torch.bfloat16), randn(B, Lr, P, N, dtype=torch.bfloat16, seed=1)
+    g, b = randn(PP, seed=2), randn(PP, seed=3)
+    co = torch.empty(B, Lr, Lr, PP, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(x_t, y_t, co, Lr * P, Lr * P, N, batch=(B, 1, 1), a_bs=(Lr * P * N, 0, 0), b_bs=(Lr * P * N, 0, 0),
+             c_bs=(Lr * Lr * PP, 0, 0), c_row=(P, Lr * PP, P), c_col=(P, PP), act=L.ACT_BLOCK_LN32, block_ln=(g, b, 1e-5))
+    outer = torch.einsum("biun,bjvn->bijuv", x_t.float(), y_t.float()).reshape(B, Lr, Lr, PP)
+    ref = torch.nn.functional.layer_norm(outer, (PP,), g, b, 1e-5)
+    assert rel_err(co, ref) < 1.5e-2
+
+
 def test_softmax_and_tied():
     B, H, Lr = 2, 3, 50
     lg = randn(B, H, Lr, Lr) * 4
