@@ -214,6 +214,25 @@ def test_coord_update(mode, k):
         assert rel2(st, rs) < 0.3 and rel2(xo, rx) < 0.05
 
 
+def test_coord_update_config5_shape():
+    """BASELINE.json configs[4] geometry for the structure module: L = 256 residues, k = 128 neighbours (kNN rule + the
+    |i-j| < 9 band: ~130 edges per node), d_node = d_edge = d_state = 32; one sample (samples are independent), exact-fp32
+    mode against the CPU oracle."""
+    R.set_compute_dtype(torch.float32)
+    try:
+        L5, k5, dm, dp = 256, 128, 64, 32
+        m = build(lambda: R.CoordUpdateWithMsaAndPair(dm, dp, 32, 32, 32, n_neighbors=k5, p_dropout=0.0))
+        msa, pair, xyz = rn(1, 4, L5, dm), rn(1, L5, L5, dp), xyz_trace(1, L5)
+        seq = torch.randint(0, 21, (1, L5), generator=torch.Generator().manual_seed(1))
+        oh = torch.nn.functional.one_hot(seq, 21).float()
+        aa = torch.arange(L5).unsqueeze(0)
+        st, xo = m(xyz.to(DEV), msa.to(DEV), pair.to(DEV), aa.to(DEV), oh.to(DEV))
+        rs, rx = O.coord_update(state(m), "m", xyz, msa, pair, aa, oh, k5, 32)
+        assert rel(st, rs) < 5e-4 and rel(xo, rx) < 5e-4
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+
+
 def test_msa_update_with_pair_and_coord(mode):
     m = build(lambda: R.MsaUpdateWithPairAndCoord(DM, DS, 32, 4 * DM, p_dropout=0.0))
     msa, st, xyz = rn(B, N, Lr, DM), rn(B, Lr, DS), xyz_trace(B, Lr)
