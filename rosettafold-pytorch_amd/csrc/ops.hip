@@ -151,6 +151,77 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int6
   }
 }
 
+// Residual-stream LayerNorm, eight rows per wave: lane (r = lane/8, q = lane%8) owns the float4 chunks q, q+8, ... of row r
+// (KPL chunks per lane: 9 for D = 288, 12 for D = 384), so every load instruction covers 8 rows x 128 contiguous bytes, the
+// row statistics are 3-step reductions inside 8-lane groups, and gamma / beta stay in registers.  The one-row-per-wave
+// kernel above issues ~150 vector instructions per 1.1 KB row (two of 64 lanes hold a second chunk, every lane pays for
+// it) and is ALU-bound at ~4.5 TB/s; this form needs ~27 per row and runs at the streaming rate of a fp32 -> bf16 cast.
+template <int KPL>
+__global__ __launch_bounds__(256) void layernorm_rows8_kernel(const float* x, int64_t x_ld, void* y, int y_dt, int64_t y_ld,
+                                                              int64_t rows, const float* gamma, const float* beta, float eps,
+                                                              int act) {
+  constexpr int D = KPL * 32;
+  const int lane = threadIdx.x & 63;
+  const int r = lane >> 3, q = lane & 7;
+  float4 g[KPL], b[KPL];
+#pragma unroll
+  for (int k = 0; k < KPL; ++k) {
+    g[k] = gamma ? *(const float4*)(gamma + 4 * (q + 8 * k)) : make_float4(1.f, 1.f, 1.f, 1.f);
+    b[k] = beta ? *(const float4*)(beta + 4 * (q + 8 * k)) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t row0 = wid * 8; row0 < rows; row0 += nw * 8) {
+    const int64_t row = row0 + r;
+    const bool ok = row < rows;
+    float4 v[KPL];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v[k] = *(const float4*)(x + row * x_ld + 4 * (q + 8 * k));
+    }
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    const float mean = s * (1.0f / D);
+    float qq = 0.f;
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+      const float a0 = v[k].x - mean, a1 = v[k].y - mean, a2 = v[k].z - mean, a3 = v[k].w - mean;
+      qq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    qq += __shfl_xor(qq, 1, 64);
+    qq += __shfl_xor(qq, 2, 64);
+    qq += __shfl_xor(qq, 4, 64);
+    const float rstd = rsqrtf(qq * (1.0f / D) + eps);
+    if (!ok) continue;
+#pragma unroll
+    for (int k = 0; k < KPL; ++k) {
+      float o[4] = {(v[k].x - mean) * rstd * g[k].x + b[k].x, (v[k].y - mean) * rstd * g[k].y + b[k].y,
+                    (v[k].z - mean) * rstd * g[k].z + b[k].z, (v[k].w - mean) * rstd * g[k].w + b[k].w};
+      if (act == RF_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+      } else if (act == RF_ACT_LEAKY) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.01f * o[e];
+      }
+      const int c = q + 8 * k;
+      if (y_dt == RF_F32) {
+        *(float4*)((float*)y + row * y_ld + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        uint2 w;
+        w.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+        w.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+        *(uint2*)((bf16_t*)y + row * y_ld + 4 * c) = w;
+      }
+    }
+  }
+}
+
 // bf16-input twin (the 1024-wide outer-product rows, rf.py:416): 16-byte loads of 8 bf16, NCH chunks per lane
 template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_vec_bf16_kernel(const bf16_t* x, int64_t x_ld, void* y, int y_dt, int64_t y_ld,
@@ -278,6 +349,14 @@ static int launch_ln(const void* x, int x_dt, int64_t x_ld, void* y, int y_dt, i
   if (rows <= 0 || D <= 0 || D > 2304) return RF_EINVAL;
   if (!SYM && x_dt == RF_F32 && groups <= 1 && D % 4 == 0 && D >= 128 && D <= 1024 && x_ld % 4 == 0 && y_ld % 4 == 0 &&
       ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (!g || (((uintptr_t)g % 16) == 0 && ((uintptr_t)b % 16) == 0))) {
+    if ((D == 288 || D == 384) && groups <= 1 && !getenv("RF_LN_ROWS1")) {
+      const unsigned gr = (unsigned)(rows < 65536 ? cdiv(rows, 32) : 2048);
+      if (D == 288)
+        hipLaunchKernelGGL((layernorm_rows8_kernel<9>), dim3(gr), dim3(256), 0, s, (const float*)x, x_ld, y, y_dt, y_ld, rows, g, b, eps, act);
+      else
+        hipLaunchKernelGGL((layernorm_rows8_kernel<12>), dim3(gr), dim3(256), 0, s, (const float*)x, x_ld, y, y_dt, y_ld, rows, g, b, eps, act);
+      return rf_launch_status();
+    }
     const unsigned gv = (unsigned)(rows < 8192 * LN_RPI ? cdiv(rows, 4 * LN_RPI) : 2048);
     if (D <= 512)
       hipLaunchKernelGGL((layernorm_vec_kernel<2, LN_RPI>), dim3(gv), dim3(256), 0, s, (const float*)x, x_ld, y, y_dt, y_ld, rows, D, g, b, eps, act);

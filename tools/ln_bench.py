@@ -16,3 +16,7 @@ for rows, D in [(262144, 288), (131072, 384), (262144, 1024)]:
     y = torch.empty(rows, D, device="cuda", dtype=torch.bfloat16)
     t = timeit(lambda: ops.layernorm(x, g, b, out=y))
     print(f"rows {rows} D {D}: {t*1e3:.1f} us, {rows*D*6/t/1e6:.0f} GB/s", flush=True)
+# reference points on the same device: fp32 -> bf16 cast (same bytes as LayerNorm) and an fp32 copy, both PyTorch kernels
+x = torch.randn(262144, 288, device="cuda"); y = torch.empty(262144, 288, device="cuda", dtype=torch.bfloat16); z = torch.empty_like(x)
+t = timeit(lambda: y.copy_(x)); print(f"torch cast fp32->bf16 (262144 x 288): {t*1e3:.1f} us, {262144*288*6/t/1e6:.0f} GB/s")
+t = timeit(lambda: z.copy_(x)); print(f"torch copy fp32 (262144 x 288): {t*1e3:.1f} us, {262144*288*8/t/1e6:.0f} GB/s")
