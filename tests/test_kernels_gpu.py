@@ -276,6 +276,21 @@ def test_gemm_block_layernorm_epilogue():
     assert rel_err(co, ref) < 1.5e-2
 
 
+@pytest.mark.parametrize("n", [4 * 1000 + 4, 1001, 1 << 20])
+def test_axpby(n):
+    """y = a x + b z: vectorised (n % 4 == 0) and scalar paths, mixed dtypes, in place."""
+    x, z = randn(n), randn(n, seed=1)
+    y = ops.axpby(x, 0.5, z, 0.25, torch.empty(n, device=DEV, dtype=torch.float32))
+    assert rel_err(y, 0.5 * x + 0.25 * z) < 1e-6
+    yb = ops.axpby(x, 0.5, z.bfloat16(), 0.25, torch.empty(n, device=DEV, dtype=torch.bfloat16))
+    assert rel_err(yb, 0.5 * x + 0.25 * z.bfloat16().float()) < 1e-2
+    x2 = x.clone()
+    ops.axpby(x2, 1.0, z, 1.0, x2)
+    assert rel_err(x2, x + z) < 1e-6
+    ys = ops.axpby(x, 2.0, None, 0.0, torch.empty(n, device=DEV, dtype=torch.float32))
+    assert rel_err(ys, 2.0 * x) < 1e-6
+
+
 def test_softmax_and_tied():
     B, H, Lr = 2, 3, 50
     lg = randn(B, H, Lr, Lr) * 4
