@@ -26,6 +26,24 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// 4-element accessors: 16-byte (fp32) / 8-byte (bf16)
+__device__ __forceinline__ float4 ld4(const void* p, int dt, int64_t e) {
+  if (dt == RF_F32) return *(const float4*)((const float*)p + e);
+  const uint2 u = *(const uint2*)((const bf16_t*)p + e);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(void* p, int dt, int64_t e, float4 v) {
+  if (dt == RF_F32) {
+    *(float4*)((float*)p + e) = v;
+  } else {
+    uint2 w;
+    w.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+    w.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+    *(uint2*)((bf16_t*)p + e) = w;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, the row lives in registers (NV values per lane)
 // ------------------------------------------------------------------------------------------------
@@ -156,10 +174,10 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int6
 // row statistics are 3-step reductions inside 8-lane groups, and gamma / beta stay in registers.  The one-row-per-wave
 // kernel above issues ~150 vector instructions per 1.1 KB row (two of 64 lanes hold a second chunk, every lane pays for
 // it) and is ALU-bound at ~4.5 TB/s; this form needs ~27 per row and runs at the streaming rate of a fp32 -> bf16 cast.
-template <int KPL>
+template <int KPL, bool SYM = false>
 __global__ __launch_bounds__(256) void layernorm_rows8_kernel(const float* x, int64_t x_ld, void* y, int y_dt, int64_t y_ld,
                                                               int64_t rows, const float* gamma, const float* beta, float eps,
-                                                              int act) {
+                                                              int act, int Lsym = 0) {
   constexpr int D = KPL * 32;
   const int lane = threadIdx.x & 63;
   const int r = lane >> 3, q = lane & 7;
@@ -180,6 +198,17 @@ __global__ __launch_bounds__(256) void layernorm_rows8_kernel(const float* x, in
     for (int k = 0; k < KPL; ++k) {
       v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) v[k] = *(const float4*)(x + row * x_ld + 4 * (q + 8 * k));
+    }
+    if constexpr (SYM) {  // row = (b,i,j) of a [B,L,L,D] tensor: normalise 0.5 * (x[b,i,j] + x[b,j,i])  (rf.py:550-556)
+      if (ok) {
+        const int64_t j = row % Lsym, i = (row / Lsym) % Lsym, bb = row / ((int64_t)Lsym * Lsym);
+        const float* xp = x + ((bb * Lsym + j) * Lsym + i) * x_ld;
+#pragma unroll
+        for (int k = 0; k < KPL; ++k) {
+          const float4 t = *(const float4*)(xp + 4 * (q + 8 * k));
+          v[k] = make_float4(0.5f * (v[k].x + t.x), 0.5f * (v[k].y + t.y), 0.5f * (v[k].z + t.z), 0.5f * (v[k].w + t.w));
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < KPL; ++k) s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
@@ -347,6 +376,15 @@ template <bool SYM>
 static int launch_ln(const void* x, int x_dt, int64_t x_ld, void* y, int y_dt, int64_t y_ld, int64_t rows, int D,
                      const float* g, const float* b, float eps, int L, int groups, int act, hipStream_t s) {
   if (rows <= 0 || D <= 0 || D > 2304) return RF_EINVAL;
+  if (SYM && x_dt == RF_F32 && (D == 288 || D == 384) && x_ld % 4 == 0 && y_ld % 4 == 0 && ((uintptr_t)x % 16) == 0 &&
+      ((uintptr_t)y % 16) == 0 && (!g || (((uintptr_t)g % 16) == 0 && ((uintptr_t)b % 16) == 0))) {
+    const unsigned gr = (unsigned)(rows < 65536 ? cdiv(rows, 32) : 2048);
+    if (D == 288)
+      hipLaunchKernelGGL((layernorm_rows8_kernel<9, true>), dim3(gr), dim3(256), 0, s, (const float*)x, x_ld, y, y_dt, y_ld, rows, g, b, eps, act, L);
+    else
+      hipLaunchKernelGGL((layernorm_rows8_kernel<12, true>), dim3(gr), dim3(256), 0, s, (const float*)x, x_ld, y, y_dt, y_ld, rows, g, b, eps, act, L);
+    return rf_launch_status();
+  }
   if (!SYM && x_dt == RF_F32 && groups <= 1 && D % 4 == 0 && D >= 128 && D <= 1024 && x_ld % 4 == 0 && y_ld % 4 == 0 &&
       ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (!g || (((uintptr_t)g % 16) == 0 && ((uintptr_t)b % 16) == 0))) {
     if ((D == 288 || D == 384) && groups <= 1 && !getenv("RF_LN_ROWS1")) {
@@ -833,23 +871,7 @@ __global__ __launch_bounds__(256) void axpby_kernel(const void* x, int x_dt, flo
   }
 }
 
-// 4 elements per thread and iteration, 16-byte (fp32) / 8-byte (bf16) accesses, two independent groups in flight
-__device__ __forceinline__ float4 ld4(const void* p, int dt, int64_t e) {
-  if (dt == RF_F32) return *(const float4*)((const float*)p + e);
-  const uint2 u = *(const uint2*)((const bf16_t*)p + e);
-  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                     __uint_as_float(u.y & 0xffff0000u));
-}
-__device__ __forceinline__ void st4(void* p, int dt, int64_t e, float4 v) {
-  if (dt == RF_F32) {
-    *(float4*)((float*)p + e) = v;
-  } else {
-    uint2 w;
-    w.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-    w.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
-    *(uint2*)((bf16_t*)p + e) = w;
-  }
-}
+// 4 elements per thread and iteration, two independent groups in flight (ld4 / st4: see the top of the file)
 __global__ __launch_bounds__(256) void axpby_vec_kernel(const void* x, int x_dt, float a, const void* z, int z_dt, float b,
                                                         void* y, int y_dt, int64_t n4) {
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -994,9 +1016,30 @@ __global__ __launch_bounds__(256) void tile_1d_kernel(const float* m1, void* fea
   }
 }
 
+// 4 channels per thread (P2 % 4 == 0, 16-byte loads, 8/16-byte stores): the scalar form spends ~100 integer instructions per
+// 2-byte store
+__global__ __launch_bounds__(256) void tile_1d_vec_kernel(const float* m1, void* feat, int dt, int64_t ld_, int c0, int L,
+                                                          int P2, int64_t total4) {
+  const int cpr = (2 * P2) >> 2;  // 4-channel chunks per (b,i,j)
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
+    const int c = (int)(e % cpr) * 4;
+    const int64_t r = e / cpr;
+    const int j = r % L, i = (r / L) % L;
+    const int64_t b = r / ((int64_t)L * L);
+    const float4 v = c < P2 ? *(const float4*)(m1 + (b * L + i) * P2 + c) : *(const float4*)(m1 + (b * L + j) * P2 + (c - P2));
+    st4(feat, dt, r * ld_ + c0 + c, v);
+  }
+}
+
 extern "C" int rf_tile_1d_feats(const float* msa1d, void* feat, int dtype, int64_t feat_ld, int c0, int B, int L, int P2,
                                 void* stream) {
   RF_CHECK_DT(dtype);
+  if (P2 % 4 == 0 && c0 % 4 == 0 && feat_ld % 4 == 0 && ((uintptr_t)msa1d % 16) == 0 && ((uintptr_t)feat % 16) == 0) {
+    const int64_t total4 = (int64_t)B * L * L * (2 * P2 / 4);
+    hipLaunchKernelGGL(tile_1d_vec_kernel, dim3(min(cdiv(total4, 256), 32768u)), dim3(256), 0, (hipStream_t)stream, msa1d, feat,
+                       dtype, feat_ld, c0, L, P2, total4);
+    return rf_launch_status();
+  }
   const int64_t total = (int64_t)B * L * L * 2 * P2;
   hipLaunchKernelGGL(tile_1d_kernel, dim3(min(cdiv(total, 256), 32768u)), dim3(256), 0, (hipStream_t)stream, msa1d, feat,
                      dtype, feat_ld, c0, L, P2, total);

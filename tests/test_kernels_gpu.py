@@ -291,6 +291,29 @@ def test_axpby(n):
     assert rel_err(ys, 2.0 * x) < 1e-6
 
 
+@pytest.mark.parametrize("D,Lr", [(288, 24), (384, 10), (96, 12)])
+def test_sym_layernorm(D, Lr):
+    """LayerNorm (no affine) of the symmetrised pair tensor 0.5 * (x + x^T) in one pass (rf.py:550-566)."""
+    x = randn(2, Lr, Lr, D) * 2 + 0.3
+    ref = torch.nn.functional.layer_norm(0.5 * (x + x.transpose(1, 2)), (D,))
+    assert rel_err(ops.sym_layernorm(x, torch.float32), ref) < 1e-5
+    assert rel_err(ops.sym_layernorm(x, torch.bfloat16), ref) < 1e-2
+
+
+def test_tile_1d_feats():
+    """feat[b,i,j,c0 + c] = m[b,i,c], feat[b,i,j,c0 + P2 + c] = m[b,j,c] (rf.py:476-485), vectorised path."""
+    B, Lr, P2, Kf, c0 = 2, 9, 64, 200, 32
+    m1 = randn(B, Lr, P2)
+    for dt in (torch.bfloat16, torch.float32):
+        feat = torch.zeros(B, Lr, Lr, Kf, device=DEV, dtype=dt)
+        ops.tile_1d_feats(m1, feat, Kf, c0, B, Lr, P2)
+        ref = torch.zeros(B, Lr, Lr, Kf, device=DEV)
+        ref[..., c0:c0 + P2] = m1[:, :, None, :]
+        ref[..., c0 + P2:c0 + 2 * P2] = m1[:, None, :, :]
+        assert rel_err(feat, ref) < (1e-2 if dt == torch.bfloat16 else 1e-7)
+        assert (feat[..., :c0] == 0).all() and (feat[..., c0 + 2 * P2:] == 0).all()
+
+
 def test_softmax_and_tied():
     B, H, Lr = 2, 3, 50
     lg = randn(B, H, Lr, Lr) * 4
