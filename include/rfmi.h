@@ -139,7 +139,11 @@ int rf_weighted_msa_sum(const void* x, int dtype, const float* w, float* y, int6
 /* InstanceNorm2d(affine, eps) on NHWC (rf.py:453,457; resnet.py:29,39,63) in two steps:
  * stats: sums[b,c,0..1] += (sum, sumsq) over the L*L pixels (sums must be zeroed by the caller);
  * apply: y = act( (x-mean)*rstd*gamma + beta [+ residual] ) ; act = RF_ACT_NONE | RF_ACT_ELU. */
-int rf_instnorm_stats(const void* x, int x_dtype, void* sums /* 2*B*C doubles */, int B, int64_t HW, int C, void* stream);
+/* workspace (optional, rf_instnorm_ws_bytes bytes): per-block partial sums reduced in a fixed order -- no atomics, results
+ * bitwise reproducible run to run; with NULL the partial sums meet in fp64 atomics (sums must then be zeroed by the caller). */
+int64_t rf_instnorm_ws_bytes(int B, int64_t HW, int C);
+int rf_instnorm_stats(const void* x, int x_dtype, void* sums /* 2*B*C doubles */, int B, int64_t HW, int C, void* workspace,
+                      int64_t ws_bytes, void* stream);
 int rf_instnorm_apply(const void* x, int x_dtype, const void* sums, const float* gamma, const float* beta, float eps,
                       const float* residual, int act, void* y, int y_dtype, void* y2, int y2_dtype, int B, int64_t HW,
                       int C, void* stream);

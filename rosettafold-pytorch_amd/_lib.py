@@ -47,7 +47,8 @@ PROTOTYPES = {
     "rf_tied_logits_softmax": [vp, vp, i64, i64, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp],
     "rf_poswise": [vp, i32, i64, vp, i64, i32, i32, i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp],
     "rf_weighted_msa_sum": [vp, i32, vp, vp, i64, i32, i32, i32, i32, vp],
-    "rf_instnorm_stats": [vp, i32, vp, i32, i64, i32, vp],
+    "rf_instnorm_ws_bytes": [i32, i64, i32],  # returns int64
+    "rf_instnorm_stats": [vp, i32, vp, i32, i64, i32, vp, i64, vp],
     "rf_instnorm_apply": [vp, i32, vp, vp, vp, f32, vp, i32, vp, i32, vp, i32, i32, i64, i32, vp],
     "rf_msa_embed": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "rf_pair_embed": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
@@ -85,6 +86,7 @@ for _name, _args in PROTOTYPES.items():
     _fn = getattr(lib, _name)  # AttributeError if the library does not export it
     _fn.argtypes = _args
     _fn.restype = C.c_int
+lib.rf_instnorm_ws_bytes.restype = C.c_int64
 lib.rf_build_info.restype = C.c_char_p
 lib.rf_build_info.argtypes = []
 

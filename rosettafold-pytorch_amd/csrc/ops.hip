@@ -628,13 +628,12 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const void* x, int 
 
 // ---- vectorised fast paths (x bf16 NHWC, C % 8 == 0): 16-byte loads, 8 channels per thread -------------------
 #define INV_PIX 512  // pixels per block in the vectorised statistics kernel
-__global__ __launch_bounds__(256) void instnorm_stats_vec_kernel(const bf16_t* x, double* sums, int64_t HW, int C) {
-  extern __shared__ float sm[];  // [2][C]
+__global__ __launch_bounds__(256) void instnorm_stats_vec_kernel(const bf16_t* x, double* sums, float* partials, int64_t HW,
+                                                                 int C) {
+  extern __shared__ float sm[];  // [ppi][2][C]: one slot per pixel group, summed in a fixed order (run-to-run identical)
   const int b = blockIdx.y;
   const int nch = C >> 3;
   const int ppi = 256 / nch;  // pixels handled per iteration
-  for (int i = threadIdx.x; i < 2 * C; i += 256) sm[i] = 0.f;
-  __syncthreads();
   const int64_t p0 = (int64_t)blockIdx.x * INV_PIX;
   const int64_t p1 = p0 + INV_PIX < HW ? p0 + INV_PIX : HW;
   const int ch = threadIdx.x % nch, po = threadIdx.x / nch;
@@ -662,15 +661,28 @@ __global__ __launch_bounds__(256) void instnorm_stats_vec_kernel(const bf16_t* x
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      atomicAdd(&sm[ch * 8 + e], s[e]);
-      atomicAdd(&sm[C + ch * 8 + e], q[e]);
+      sm[(po * 2 + 0) * C + ch * 8 + e] = s[e];
+      sm[(po * 2 + 1) * C + ch * 8 + e] = q[e];
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(&sums[((int64_t)b * C + c) * 2 + 0], (double)sm[c]);
-    atomicAdd(&sums[((int64_t)b * C + c) * 2 + 1], (double)sm[C + c]);
+  for (int c = threadIdx.x; c < 2 * C; c += 256) {  // c < C: sum, c >= C: sum of squares
+    float t = 0.f;
+    for (int g = 0; g < ppi; ++g) t += sm[g * 2 * C + c];
+    if (partials)  // deterministic path: per-block partials, reduced in block order by instnorm_finalize_kernel
+      partials[((int64_t)b * gridDim.x + blockIdx.x) * 2 * C + c] = t;
+    else
+      atomicAdd(&sums[((int64_t)b * C + (c < C ? c : c - C)) * 2 + (c < C ? 0 : 1)], (double)t);
   }
+}
+
+__global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* partials, double* sums, int nblk, int C) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * C) return;
+  double t = 0.0;
+  for (int k = 0; k < nblk; ++k) t += (double)partials[((int64_t)b * nblk + k) * 2 * C + c];
+  sums[((int64_t)b * C + (c < C ? c : c - C)) * 2 + (c < C ? 0 : 1)] = t;
 }
 
 __global__ __launch_bounds__(256) void instnorm_apply_vec_kernel(const bf16_t* x, const double* sums, const float* gamma,
@@ -725,11 +737,24 @@ __global__ __launch_bounds__(256) void instnorm_apply_vec_kernel(const bf16_t* x
   }
 }
 
-extern "C" int rf_instnorm_stats(const void* x, int x_dtype, void* sums, int B, int64_t HW, int C, void* stream) {
+/* workspace size for the atomics-free (bitwise reproducible) statistics path */
+extern "C" int64_t rf_instnorm_ws_bytes(int B, int64_t HW, int C) {
+  return (int64_t)B * cdiv(HW, INV_PIX) * 2 * C * (int64_t)sizeof(float);
+}
+
+extern "C" int rf_instnorm_stats(const void* x, int x_dtype, void* sums, int B, int64_t HW, int C, void* workspace,
+                                 int64_t ws_bytes, void* stream) {
   RF_CHECK_DT(x_dtype);
   if (x_dtype == RF_BF16 && C % 8 == 0 && C / 8 <= 256 && ((uintptr_t)x % 16) == 0) {
-    hipLaunchKernelGGL(instnorm_stats_vec_kernel, dim3(cdiv(HW, INV_PIX), B), dim3(256), 2 * C * sizeof(float),
-                       (hipStream_t)stream, (const bf16_t*)x, (double*)sums, HW, C);
+    const unsigned nblk = cdiv(HW, INV_PIX);
+    const int ppi = 256 / (C / 8);
+    // with a workspace of rf_instnorm_ws_bytes(B, HW, C) the reduction is free of atomics and bitwise reproducible
+    float* partials = (workspace && ws_bytes >= (int64_t)B * nblk * 2 * C * (int64_t)sizeof(float)) ? (float*)workspace : nullptr;
+    hipLaunchKernelGGL(instnorm_stats_vec_kernel, dim3(nblk, B), dim3(256), (size_t)ppi * 2 * C * sizeof(float),
+                       (hipStream_t)stream, (const bf16_t*)x, (double*)sums, partials, HW, C);
+    if (partials)
+      hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(2 * C, 256), B), dim3(256), 0, (hipStream_t)stream, partials,
+                         (double*)sums, (int)nblk, C);
     return rf_launch_status();
   }
   hipLaunchKernelGGL(instnorm_stats_kernel, dim3(cdiv(HW, IN_PIX), B), dim3(256), 0, (hipStream_t)stream, x, x_dtype,

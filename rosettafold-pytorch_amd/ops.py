@@ -170,7 +170,10 @@ def instnorm(x, gamma, beta, *, eps=1e-6, residual=None, act=L.ACT_NONE, out_dty
     B, H, W, Cc = x.shape
     _need_cuda(x, gamma, beta, residual)
     sums = torch.zeros(B * Cc * 2, device=x.device, dtype=torch.float64)
-    check(lib.rf_instnorm_stats(ptr(x), dcode(x.dtype), ptr(sums), B, H * W, Cc, stream()), "rf_instnorm_stats")
+    ws_bytes = int(lib.rf_instnorm_ws_bytes(B, H * W, Cc))  # atomics-free, bitwise reproducible statistics
+    ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+    check(lib.rf_instnorm_stats(ptr(x), dcode(x.dtype), ptr(sums), B, H * W, Cc, ptr(ws), ws_bytes, stream()),
+          "rf_instnorm_stats")
     y = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
     y2 = torch.empty(x.shape, device=x.device, dtype=out2_dtype) if out2_dtype is not None else None
     check(lib.rf_instnorm_apply(ptr(x), dcode(x.dtype), ptr(sums), ptr(gamma), ptr(beta), eps, ptr(residual), act,

@@ -313,3 +313,20 @@ def test_long_sequence_smoke():
     assert logits["dist"].shape == (1, Ll, Ll, 37) and xyz.shape == (1, Ll, 3, 3) and plddt.shape == (1, Ll)
     for t in list(logits.values()) + [xyz, plddt]:
         assert torch.isfinite(t).all()
+
+def test_forward_is_bitwise_reproducible():
+    """No kernel on the path uses atomics or a data race: two forwards on the same inputs agree bit for bit (the network is
+    discontinuous, so a one-ulp difference anywhere would otherwise grow to O(1) in the coordinates)."""
+    R.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(5)
+    m = R.RoseTTAFold(d_msa=96, d_pair=64, d_node=16, d_edge=16, d_state=16, n_two_track_blocks=1, n_three_track_blocks=2,
+                      n_encoder_layers=1, max_len=70, n_neighbors=[16, 16], p_dropout=0.0).to(DEV).eval()
+    g = torch.Generator().manual_seed(0)
+    msa = torch.randint(0, 21, (2, 8, 64), generator=g).to(DEV)
+    seq, aa = msa[:, 0].clone(), torch.arange(64).unsqueeze(0).repeat(2, 1).to(DEV)
+    with torch.no_grad():
+        a = m(msa, seq, aa)
+        b = m(msa, seq, aa)
+    for k in a[0]:
+        assert torch.equal(a[0][k], b[0][k]), k
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
