@@ -610,7 +610,9 @@ extern "C" int rf_weighted_msa_sum(const void* x, int dtype, const float* w, flo
 // InstanceNorm over NHWC: statistics (fp64 atomics of per-block fp32 partials) + apply
 // ------------------------------------------------------------------------------------------------
 #define IN_PIX 128  // pixels per block
-__global__ __launch_bounds__(256) void instnorm_stats_kernel(const void* x, int dt, double* sums, int64_t HW, int C) {
+__global__ void instnorm_finalize_kernel(const float* partials, double* sums, int nblk, int C);
+__global__ __launch_bounds__(256) void instnorm_stats_kernel(const void* x, int dt, double* sums, float* partials, int64_t HW,
+                                                             int C) {
   const int b = blockIdx.y;
   const int64_t p0 = (int64_t)blockIdx.x * IN_PIX;
   const int64_t p1 = p0 + IN_PIX < HW ? p0 + IN_PIX : HW;
@@ -621,8 +623,14 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const void* x, int 
       s += v;
       q = fmaf(v, v, q);
     }
-    atomicAdd(&sums[((int64_t)b * C + c) * 2 + 0], (double)s);
-    atomicAdd(&sums[((int64_t)b * C + c) * 2 + 1], (double)q);
+    if (partials) {  // deterministic path (see instnorm_finalize_kernel)
+      float* pp = partials + ((int64_t)b * gridDim.x + blockIdx.x) * 2 * C;
+      pp[c] = s;
+      pp[C + c] = q;
+    } else {
+      atomicAdd(&sums[((int64_t)b * C + c) * 2 + 0], (double)s);
+      atomicAdd(&sums[((int64_t)b * C + c) * 2 + 1], (double)q);
+    }
   }
 }
 
@@ -739,7 +747,7 @@ __global__ __launch_bounds__(256) void instnorm_apply_vec_kernel(const bf16_t* x
 
 /* workspace size for the atomics-free (bitwise reproducible) statistics path */
 extern "C" int64_t rf_instnorm_ws_bytes(int B, int64_t HW, int C) {
-  return (int64_t)B * cdiv(HW, INV_PIX) * 2 * C * (int64_t)sizeof(float);
+  return (int64_t)B * cdiv(HW, IN_PIX) * 2 * C * (int64_t)sizeof(float);  // (sized for the finer of the two block shapes)
 }
 
 extern "C" int rf_instnorm_stats(const void* x, int x_dtype, void* sums, int B, int64_t HW, int C, void* workspace,
@@ -757,8 +765,15 @@ extern "C" int rf_instnorm_stats(const void* x, int x_dtype, void* sums, int B, 
                          (double*)sums, (int)nblk, C);
     return rf_launch_status();
   }
-  hipLaunchKernelGGL(instnorm_stats_kernel, dim3(cdiv(HW, IN_PIX), B), dim3(256), 0, (hipStream_t)stream, x, x_dtype,
-                     (double*)sums, HW, C);
+  {
+    const unsigned nblk = cdiv(HW, IN_PIX);
+    float* partials = (workspace && ws_bytes >= (int64_t)B * nblk * 2 * C * (int64_t)sizeof(float)) ? (float*)workspace : nullptr;
+    hipLaunchKernelGGL(instnorm_stats_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, x, x_dtype, (double*)sums,
+                       partials, HW, C);
+    if (partials)
+      hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(2 * C, 256), B), dim3(256), 0, (hipStream_t)stream, partials,
+                         (double*)sums, (int)nblk, C);
+  }
   return rf_launch_status();
 }
 
