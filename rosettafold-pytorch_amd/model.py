@@ -671,7 +671,9 @@ class PairUpdateWithMsa(RFModule):
         coevol = self.outer_product_mean.run(xt, yt, Np)  # fp32 [B,L,L,Dp]
         # feature tensor (K padded to a multiple of 8)
         Kf = pad8(self.d_feat)
-        feat = torch.zeros(B, Lr, Lr, Kf, device=dev, dtype=T())
+        feat = torch.empty(B, Lr, Lr, Kf, device=dev, dtype=T())  # every feature column is written below; only the K padding
+        if Kf > self.d_feat:                                       # needs zeros (a full memset of this tensor is 0.38 GB)
+            feat[..., self.d_feat:].zero_()
         ln(self.ln_coevol_feat, coevol, out=feat, out_ld=Kf, out_off=0)
         ops.tile_1d_feats(msa1d, feat, Kf, Dp, B, Lr, 2 * P)
         ln(self.ln_pair, pair, out=feat, out_ld=Kf, out_off=Dp + 4 * P)

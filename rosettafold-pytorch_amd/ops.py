@@ -169,7 +169,7 @@ def instnorm(x, gamma, beta, *, eps=1e-6, residual=None, act=L.ACT_NONE, out_dty
     """InstanceNorm2d(affine) over NHWC x [B,H,W,C]; returns (y, y2) where y2 is an optional second copy."""
     B, H, W, Cc = x.shape
     _need_cuda(x, gamma, beta, residual)
-    sums = torch.zeros(B * Cc * 2, device=x.device, dtype=torch.float64)
+    sums = torch.empty(B * Cc * 2, device=x.device, dtype=torch.float64)  # fully written by the ordered finalize step
     ws_bytes = int(lib.rf_instnorm_ws_bytes(B, H * W, Cc))  # atomics-free, bitwise reproducible statistics
     ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
     check(lib.rf_instnorm_stats(ptr(x), dcode(x.dtype), ptr(sums), B, H * W, Cc, ptr(ws), ws_bytes, stream()),
