@@ -41,7 +41,8 @@ def test_linear(dtype, tol, M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(16384, 256, 288), (16384, 1536, 288), (32768, 288, 512), (16384, 288, 1152),
                                    (16384, 384, 768), (16384, 1152, 384), (16384, 128, 64), (16384, 384, 72),
-                                   (65536 + 256, 512, 96), (16384, 2304, 384), (16384, 576, 128)])
+                                   (65536 + 256, 512, 96), (16384, 2304, 384), (16384, 576, 128), (16384, 256, 112),
+                                   (16384, 192, 176)])
 def test_gemm_persistent_fast_path(M, N, K):
     """Plain row-major panels with M % 256 == 0 take the persistent kernel (gemm_fast.hip): every output type /
     bias / ReLU / residual specialisation, K tails of 8..56, more tiles than CUs and fewer."""
