@@ -108,6 +108,11 @@ int rf_sym_layernorm(const float* pair, void* y, int y_dtype, int B, int L, int 
 int rf_softmax(const float* x, int64_t x_rs, int64_t x_cs, void* y, int y_dtype, int64_t y_rs, int64_t rows,
                int cols, float scale, void* stream);
 
+/* nbatch such problems in one launch: problem z reads x + z*x_bs, writes y + z*y_bs (the per-(layer, head) softmaxes of one
+ * MsaUpdateWithPair stack, rf.py:569). */
+int rf_softmax_batched(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_cs, void* y, int y_dtype, int64_t y_bs,
+                       int64_t y_rs, int64_t rows, int cols, float scale, int nbatch, void* stream);
+
 /* Tied-attention softmax (rf.py:255,261-265): logits fp32 [B,H,L,L] -> att T [B,H,L,L] and, when
  * att_sym != NULL, the symmetrised map 0.5*(att+att^T) as fp32 [B,L,L,H] (written with ld sym_ld). */
 int rf_tied_softmax(const float* logits, void* att, int att_dtype, float* att_sym, int64_t sym_ld, int B, int H,

@@ -43,6 +43,7 @@ PROTOTYPES = {
     "rf_layernorm": [vp, i32, i64, vp, i32, i64, i64, i32, vp, vp, f32, i32, i32, vp],
     "rf_sym_layernorm": [vp, vp, i32, i32, i32, i32, f32, vp],
     "rf_softmax": [vp, i64, i64, vp, i32, i64, i64, i32, f32, vp],
+    "rf_softmax_batched": [vp, i64, i64, i64, vp, i32, i64, i64, i64, i32, f32, i32, vp],
     "rf_tied_softmax": [vp, vp, i32, vp, i64, i32, i32, i32, vp],
     "rf_tied_logits_softmax": [vp, vp, i64, i64, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp],
     "rf_poswise": [vp, i32, i64, vp, i64, i32, i32, i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp],

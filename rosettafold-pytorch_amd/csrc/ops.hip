@@ -465,6 +465,33 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float* x, int64_t x_
   for (int c = lane; c < cols; c += 64) st(y, y_dt, row * y_rs + c, __expf(xr[c * x_cs] * scale - mx) * inv);
 }
 
+// nbatch independent softmax problems in one launch: problem z reads x + z*x_bs and writes y + z*y_bs (elements)
+__global__ __launch_bounds__(256) void softmax_batched_kernel(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_cs, void* y,
+                                                              int y_dt, int64_t y_bs, int64_t y_rs, int64_t rows, int cols,
+                                                              float scale, int nbatch) {
+  const int lane = threadIdx.x & 63;
+  const int64_t gr = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gr >= rows * nbatch) return;
+  const int64_t z = gr / rows, row = gr % rows;
+  const float* xr = x + z * x_bs + row * x_rs;
+  float mx = -INFINITY;
+  for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, xr[c * x_cs] * scale);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += __expf(xr[c * x_cs] * scale - mx);
+  const float inv = 1.f / wave_sum(s);
+  for (int c = lane; c < cols; c += 64) st(y, y_dt, z * y_bs + row * y_rs + c, __expf(xr[c * x_cs] * scale - mx) * inv);
+}
+
+extern "C" int rf_softmax_batched(const float* x, int64_t x_bs, int64_t x_rs, int64_t x_cs, void* y, int y_dtype, int64_t y_bs,
+                                  int64_t y_rs, int64_t rows, int cols, float scale, int nbatch, void* stream) {
+  RF_CHECK_DT(y_dtype);
+  if (rows <= 0 || cols <= 0 || nbatch <= 0) return RF_EINVAL;
+  hipLaunchKernelGGL(softmax_batched_kernel, dim3(cdiv(rows * nbatch, 4)), dim3(256), 0, (hipStream_t)stream, x, x_bs, x_rs, x_cs,
+                     y, y_dtype, y_bs, y_rs, rows, cols, scale, nbatch);
+  return rf_launch_status();
+}
+
 extern "C" int rf_softmax(const float* x, int64_t x_rs, int64_t x_cs, void* y, int y_dtype, int64_t y_rs, int64_t rows,
                           int cols, float scale, void* stream) {
   RF_CHECK_DT(y_dtype);

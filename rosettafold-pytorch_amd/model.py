@@ -830,13 +830,10 @@ def pair_to_att(layers, pair):
     wc, bc = holder.cached(("att_fold", nl), fold)
     logits = ops.linear(xs, wc, bc, out_dtype=F32)  # [B,L,L,nl*H]
     NH = nl * H
-    atts = []
-    for li in range(nl):
-        att = torch.empty(H, B, Lr, Lr, device=pair.device, dtype=T())
-        for h in range(H):
-            ops.softmax(logits, li * H + h, Lr * NH, NH, att, h * B * Lr * Lr, Lr, B * Lr, Lr)
-        atts.append(att)
-    return atts
+    # every (layer, head) softmax in one launch: problem z = li*H + h is column z of the logits
+    att_all = torch.empty(nl, H, B, Lr, Lr, device=pair.device, dtype=T())
+    ops.softmax_batched(logits, 1, Lr * NH, NH, att_all, B * Lr * Lr, Lr, B * Lr, Lr, NH)
+    return [att_all[li] for li in range(nl)]
 
 
 class MsaUpdateWithPair(RFModule):

@@ -136,6 +136,12 @@ def softmax(x, x_off, x_rs, x_cs, y, y_off, y_rs, rows, cols, scale=1.0):
           "rf_softmax")
 
 
+def softmax_batched(x, x_bs, x_rs, x_cs, y, y_bs, y_rs, rows, cols, nbatch, scale=1.0):
+    _need_cuda(x, y)
+    check(lib.rf_softmax_batched(ptr(x), x_bs, x_rs, x_cs, ptr(y), dcode(y.dtype), y_bs, y_rs, rows, cols, scale, nbatch,
+                                 stream()), "rf_softmax_batched")
+
+
 def tied_logits_softmax(q, k, b_stride, n_stride, l_stride, att, att_sym, B, H, N, L_, d_head):
     """att[b,h,i,:] = softmax_j(sum_{n,d} q k) in one launch (csrc/tied.hip); q, k: bf16 views into the projection output."""
     _need_cuda(q, k, att, att_sym)
