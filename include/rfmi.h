@@ -126,6 +126,29 @@ int rf_tied_softmax(const float* logits, void* att, int att_dtype, float* att_sy
 int rf_tied_logits_softmax(const void* q, const void* k, int64_t b_stride, int64_t n_stride, int64_t l_stride, void* att,
                            float* att_sym, int64_t sym_ld, int B, int H, int N, int L, int d_head, void* stream);
 
+/* Attention . V of the tied attention (rf.py:257-258): out[b,n,i,h,:] = sum_j att[b,h,i,j] v[b,n,h,j,:], bf16.
+ * att: [B,H,L,L]; v / out element (b,n,h,l,d) at b*s[0] + n*s[1] + h*s[2] + l*s[3] + d (the 32-wide head slice
+ * contiguous; any layout works, a head-major v -- [.., L, 32] tiles contiguous -- is the fast one).  d_head == 32,
+ * L in {64,128,192,256}. */
+int rf_tied_av(const void* att, const void* v, const int64_t v_strides[4], void* out, const int64_t o_strides[4], int B,
+               int H, int N, int L, int d_head, void* stream);
+
+/* Tied MSA-row attention core in one call (rf.py:252-265): logits + softmax, optional symmetrised map, attention . V.
+ *   att[b,h,i,:] = softmax_j( sum_{n,d} (w[b,h,n,i] * qscale) q[b,n,h,i,d] k[b,n,h,j,d] ),  out = att . v
+ * q / k share qk_strides {b,n,h,l}; w (fp32, may be NULL = q already scaled) has strides {b,h,n} with l contiguous: the
+ * position weights of rf.py:252 are applied inside the logits kernel instead of a pass over q.  att: bf16 [B,H,L,L]
+ * (caller-owned workspace and result); att_sym as in rf_tied_softmax (may be NULL). */
+int rf_tied_attention(const void* q, const void* k, const void* v, const int64_t qk_strides[4], const int64_t v_strides[4],
+                      const float* w, const int64_t w_strides[3], float qscale, void* att, float* att_sym, int64_t sym_ld,
+                      void* out, const int64_t o_strides[4], int B, int H, int N, int L, int d_head, void* stream);
+
+/* PositionWiseWeightFactor in collapsed form on the matrix pipe (rf.py:205-217):
+ *   w[b,h,n,l] = softmax_n( scale * sum_c xn[b,n,l,c] * u[b,l,h,c] ),   u[b,l,h,:] = W_k[h*dh:(h+1)*dh, :]^T to_q(x_0)[b,l,h,:]
+ * (to_k's bias is constant in n and cancels in the softmax, so the to_k projection over all N rows is never formed).
+ * xn: bf16 [B,N,L,D]; u: bf16 [B,L,H,D]; w: fp32 [B,H,N,L].  H <= 16, D % 32 == 0, N % 16 == 0, N <= 256. */
+int rf_poswise_collapsed(const void* xn, const void* u, float* w, int B, int N, int L, int D, int H, float scale,
+                         void* stream);
+
 /* PositionWiseWeightFactor core (rf.py:205-217): w[b,n,h,l] = softmax_n( scale * sum_{c<dlen} q0[b,l,h,c]*k[b,n,l,h,c] ).
  * q0: [B,L,H*dlen] (dtype q0_dtype, ld q0_ld); k: T rows [B,N,L,*] of ld k_ld, head h at column k_col0 + h*k_hstride.
  *   - direct form:    q0 = to_q(row 0), k = to_k(x), dlen = k_hstride = d_head;
@@ -142,10 +165,10 @@ int rf_weighted_msa_sum(const void* x, int dtype, const float* w, float* y, int6
                         void* stream);
 
 /* InstanceNorm2d(affine, eps) on NHWC (rf.py:453,457; resnet.py:29,39,63) in two steps:
- * stats: sums[b,c,0..1] += (sum, sumsq) over the L*L pixels (sums must be zeroed by the caller);
+ * stats: sums[b,c,0..1] = (sum, sumsq) over the L*L pixels (fully written: no zeroing needed);
  * apply: y = act( (x-mean)*rstd*gamma + beta [+ residual] ) ; act = RF_ACT_NONE | RF_ACT_ELU. */
-/* workspace (optional, rf_instnorm_ws_bytes bytes): per-block partial sums reduced in a fixed order -- no atomics, results
- * bitwise reproducible run to run; with NULL the partial sums meet in fp64 atomics (sums must then be zeroed by the caller). */
+/* workspace (MANDATORY, rf_instnorm_ws_bytes bytes): per-block partial sums reduced in a fixed order -- the library has no
+ * atomic accumulation anywhere, results are bitwise reproducible run to run; NULL / too small -> RF_EINVAL. */
 int64_t rf_instnorm_ws_bytes(int B, int64_t HW, int C);
 int rf_instnorm_stats(const void* x, int x_dtype, void* sums /* 2*B*C doubles */, int B, int64_t HW, int C, void* workspace,
                       int64_t ws_bytes, void* stream);
@@ -171,8 +194,30 @@ int rf_copy4d(const void* x, int x_dtype, const int64_t xs[4], void* y, int y_dt
 int rf_axpby(const void* x, int x_dtype, float a, const void* z, int z_dtype, float b, void* y, int y_dtype,
              int64_t n, void* stream);
 
-/* x[r,:] *= w[r]  (msa_proj * position weight, rf.py:472); x T [rows, D] in place */
-int rf_scale_rows(void* x, int dtype, const float* w, int64_t rows, int D, void* stream);
+/* y[r,:] = x[r,:] * w[r]  (msa_proj * position weight, rf.py:472); x, y T [rows, D]; y may alias x */
+int rf_scale_rows(const void* x, void* y, int dtype, const float* w, int64_t rows, int D, void* stream);
+
+/* y[0..n) = value (T); y 16-byte aligned.  Zero / one initialisation of caller-owned buffers without a framework kernel. */
+int rf_fill(void* y, int dtype, float value, int64_t n, void* stream);
+
+/* Input validation of RoseTTAFold.forward (the reference raises IndexError from nn.Embedding / tensor indexing,
+ * rf.py:73,98,115-119,155): flags[0] = a token outside [0, d_input), flags[1] = an aa_idx outside [0, max_len),
+ * flags[2] = aa_idx not strictly increasing inside a sample (the kNN edge-capacity bound then does not hold, rf.py:841-852).
+ * msa / seq / aa_idx may each be NULL (skipped).  flags: 3 x int32, zeroed by the caller. */
+int rf_check_inputs(const int64_t* msa, int64_t n_msa, const int64_t* seq, int64_t n_seq, const int64_t* aa_idx,
+                    int64_t n_idx, int L, int d_input, int max_len, int32_t* flags, void* stream);
+
+/* y[r, col0 + c] = (idx[r] == c), c < n_classes  (F.one_hot(seq, 21), rf.py:1276); y T with leading dim y_ld */
+int rf_onehot(const int64_t* idx, void* y, int dtype, int64_t y_ld, int col0, int n_classes, int64_t rows, void* stream);
+
+/* y[(b,i,j)*y_ld + col] = clamp(sign(d)*log(|d|+1), 0, 5.5), d = aa_idx[b,i]-aa_idx[b,j]  (rf.py:746-749) */
+int rf_seqsep_feature(const int64_t* aa_idx, void* y, int dtype, int64_t y_ld, int col, int B, int L, void* stream);
+
+/* Stand-alone positional encodings, fp32: two_d == 0: SinusoidalPositionalEncoding.forward (rf.py:72-76)
+ * y[b,n,l,:] = x + pe[aa_idx[b,l]] (pe [max_len, D]); two_d != 0: SinusoidalPositionalEncoding2D.forward (rf.py:95-103)
+ * y[b,i,j,:] = x + [pe[aa_idx[b,i]] | pe[aa_idx[b,j]]] (N == L, pe [max_len, D/2]).  aa_idx must be in range. */
+int rf_add_pos_enc(const float* x, const int64_t* aa_idx, const float* pe, float* y, int B, int N, int L, int D, int two_d,
+                   void* stream);
 
 /* FAVOR+ softmax-kernel features (performer-pytorch softmax_kernel as called at rf.py:313-318; third party,
  * parity unpinned).  One workgroup per (sequence, head) S.  dash = (d^-1/4 x) P^T from rf_gemm, T, laid out
@@ -225,11 +270,13 @@ int rf_dist_masked_attention(const float* q, const float* k, const float* xyz, c
 int rf_knn_mask(const float* xyz, const int64_t* aa_idx, uint8_t* mask, int B, int L, int k, int kmin, void* stream);
 
 /* Compact the dense mask into an edge list sorted by (b,i,j) (row-major torch.where order, rf.py:853):
- * src/dst node ids (b*L+i / b*L+j), eid[b,i,j] = edge id or -1, count[0] = number of edges.
- * At most min(L, k + 2*(kmin-1)) edges per row, so capacity B*L*min(L,k+2*kmin-2) suffices.
- * row_ws: 2*B*L int32 scratch. */
+ * src/dst node ids (b*L+i / b*L+j), eid[b,i,j] = edge id or -1.  count: 2 x int32 -- count[0] = min(edges, capacity)
+ * (what consumers iterate over), count[1] = the true number of edges.  src/dst hold `capacity` entries; an edge whose
+ * id would be >= capacity is DROPPED (eid = -1, nothing written) and shows up as count[1] > capacity, so the caller's
+ * buffers are never overrun.  For strictly increasing aa_idx and finite coordinates a row has at most
+ * min(L, k + 2*(kmin-1)) edges; otherwise use capacity B*L*L.  row_ws: 2*B*L int32 scratch. */
 int rf_edges_from_mask(const uint8_t* mask, int32_t* src, int32_t* dst, int32_t* eid, int32_t* count, int32_t* row_ws,
-                       int B, int L, void* stream);
+                       int B, int L, int64_t capacity, void* stream);
 
 /* Per-edge geometry (ea/modules.py:26-108): d = CA[dst]-CA[src]; r; real SH Y0..Y2 and the four equivariant
  * bases folded with the Q_J constants: basis layout [E, 1+3+3+27] floats = (0,0)[1] (0,1)[3x1] (1,0)[1x3] (1,1)[3x3x3];
@@ -247,10 +294,12 @@ int rf_se3_message(const float* R0, const float* R1, const float* basis, const f
 
 /* Graph attention (ea/modules.py:738-774): e = <k_edge, q[dst]>/sqrt(nfeat) per head, softmax over incoming edges
  * of each dst node, out[dst] = sum a * v.  k/v per-edge: k0 [E,mk0] k1 [E,mk1,3] v0 [E,mv0] v1 [E,mv1,3]; q per node.
- * One wave per (dst node, head) walks column dst of the dense eid map in fixed order (deterministic). */
+ * One wave per (dst node, head) walks column dst of the dense eid map in fixed order (deterministic).
+ * out0 / out1 rows are out0_ld / out1_ld floats apart (0 = packed: mv0 / 3*mv1), so the result can land in the leading
+ * channels of the skip-concatenation buffer (GCat, ea/modules.py:903-928). */
 int rf_se3_attention(const float* k0, const float* k1, const float* q0, const float* q1, const float* v0,
                      const float* v1, const int32_t* eid, float* out0, float* out1, int heads, int mk0, int mk1,
-                     int mv0, int mv1, int V, int L, void* stream);
+                     int mv0, int mv1, int V, int L, int64_t out0_ld, int64_t out1_ld, void* stream);
 
 /* GNormBias (ea/modules.py:391-406): y = relu(|v| + b) * v/|v| per channel, v [V, m, 2d+1]. */
 int rf_se3_norm_bias(const float* v, const float* bias, float* y, int64_t V, int m, int deg, void* stream);

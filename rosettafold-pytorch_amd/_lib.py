@@ -46,6 +46,10 @@ PROTOTYPES = {
     "rf_softmax_batched": [vp, i64, i64, i64, vp, i32, i64, i64, i64, i32, f32, i32, vp],
     "rf_tied_softmax": [vp, vp, i32, vp, i64, i32, i32, i32, vp],
     "rf_tied_logits_softmax": [vp, vp, i64, i64, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp],
+    "rf_tied_av": [vp, vp, C.POINTER(I64x4), vp, C.POINTER(I64x4), i32, i32, i32, i32, i32, vp],
+    "rf_tied_attention": [vp, vp, vp, C.POINTER(I64x4), C.POINTER(I64x4), vp, C.POINTER(I64x3), f32, vp, vp, i64, vp,
+                          C.POINTER(I64x4), i32, i32, i32, i32, i32, vp],
+    "rf_poswise_collapsed": [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp],
     "rf_poswise": [vp, i32, i64, vp, i64, i32, i32, i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp],
     "rf_weighted_msa_sum": [vp, i32, vp, vp, i64, i32, i32, i32, i32, vp],
     "rf_instnorm_ws_bytes": [i32, i64, i32],  # returns int64
@@ -62,16 +66,21 @@ PROTOTYPES = {
     "rf_graph_attention": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, f32, vp],
     "rf_dist_masked_attention": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "rf_knn_mask": [vp, vp, vp, i32, i32, i32, i32, vp],
-    "rf_edges_from_mask": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
+    "rf_edges_from_mask": [vp, vp, vp, vp, vp, vp, i32, i32, i64, vp],
     "rf_se3_edge_geometry": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, vp],
     "rf_se3_message": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, vp],
-    "rf_se3_attention": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "rf_se3_attention": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, vp],
     "rf_se3_norm_bias": [vp, vp, vp, i64, i32, i32, vp],
     "rf_se3_gram": [vp, vp, i64, i32, i32, vp],
     "rf_se3_attn_apply": [vp, vp, vp, i64, i32, i32, i32, vp],
     "rf_coord_apply": [vp, vp, vp, i64, vp],
     "rf_center_ca": [vp, vp, i64, vp],
-    "rf_scale_rows": [vp, i32, vp, i64, i32, vp],
+    "rf_scale_rows": [vp, vp, i32, vp, i64, i32, vp],
+    "rf_fill": [vp, i32, f32, i64, vp],
+    "rf_check_inputs": [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, vp],
+    "rf_onehot": [vp, vp, i32, i64, i32, i32, i64, vp],
+    "rf_seqsep_feature": [vp, vp, i32, i64, i32, i32, i32, vp],
+    "rf_add_pos_enc": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "rf_debug_gemm_stamps": [vp],
     "rf_debug_gemm_fast_stamps": [vp],
     "rf_version": [],

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "rfmi.h"
 
@@ -46,6 +47,36 @@ static inline int rf_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
+
+// Kernels that need more than 64 KB of dynamic LDS: the opt-in attribute is per device, so it is set once per
+// (kernel, device the calling thread is on) and its return code is reported.  0 = ok, else a hipError_t.
+template <auto Kernel>
+static inline int rf_enable_big_lds() {
+  static unsigned long long done = 0;  // bit d: set on device d (devices >= 64: set every call)
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return 0;
+  e = hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return (int)e;
+  if (dev >= 0 && dev < 64) done |= 1ull << dev;
+  return 0;
+}
+
+// compute units of the device the calling thread is on (cached per device)
+static inline int rf_num_cus() {
+  static int cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 64 && cus[dev]) return cus[dev];
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  if (dev >= 0 && dev < 64) cus[dev] = prop.multiProcessorCount;
+  return prop.multiProcessorCount;
+}
+
+// environment switches (A/B experiments) are read once per process, not per launch
+static inline bool rf_env_flag(const char* name) { return getenv(name) != nullptr; }
 
 // gemm_fast.hip: persistent plain-layout bf16 GEMM; returns 1 (launched, *rc = status) or 0 (descriptor does not fit)
 int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream);

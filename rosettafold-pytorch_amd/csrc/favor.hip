@@ -818,7 +818,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
 template <int LS, bool SM>
 static int launch_favor(const FavorAttnP& p, hipStream_t s) {
   const size_t lds = (size_t)FV_MPAD * 128 + 2 * (size_t)LS * 128 + (size_t)FV_DROWS * FV_CTX_LD + LS * 4 + 64;
-  int ncu = 256;
+  const int ncu = rf_num_cus() > 0 ? rf_num_cus() : 256;
   const int grid = p.nitems < ncu ? p.nitems : ncu;
   // measured (tools/favor_bench.py): the 8-wave kernel wins for the ReLU features (no AGPR traffic at <= 256
   // registers) and for the softmax features up to 128-row sequences (674 vs 720 us on the MSA-column shape; 9 spilled
@@ -827,13 +827,11 @@ static int launch_favor(const FavorAttnP& p, hipStream_t s) {
   const bool use4 = force4 || (SM && LS > 128 && !force8);
   if (use4) {
     auto k = favor_attention_kernel<LS, SM>;
-    static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-    (void)once;
+    if (const int e = rf_enable_big_lds<favor_attention_kernel<LS, SM>>()) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
   } else {
     auto k = favor_attention_kernel8<LS, SM>;
-    static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-    (void)once;
+    if (const int e = rf_enable_big_lds<favor_attention_kernel8<LS, SM>>()) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, p);
   }
   return rf_launch_status();
@@ -867,7 +865,8 @@ extern "C" int rf_favor_attention(const void* qkv, const void* pc, void* out, co
   p.nitems = n_b * n_o * n_h;
   p.eps = eps;
   p.nchunks = nchunks;
-  p.dbg = getenv("RF_FAVOR_DBG") ? atoi(getenv("RF_FAVOR_DBG")) : 0;
+  static const int dbg = getenv("RF_FAVOR_DBG") ? atoi(getenv("RF_FAVOR_DBG")) : 0;
+  p.dbg = dbg;
   hipStream_t s = (hipStream_t)stream;
   if (ls == 256) return softmax_kernel ? launch_favor<256, true>(p, s) : launch_favor<256, false>(p, s);
   if (ls == 128) return softmax_kernel ? launch_favor<128, true>(p, s) : launch_favor<128, false>(p, s);

@@ -659,13 +659,11 @@ static int launch_bf16(const GemmP& p, int64_t nblk, hipStream_t s) {
   const size_t lds = lds_bytes_for(BM, BN, BK, WGM);
   if (p.d.a_mode == RF_AMODE_CONV3X3) {
     auto k = gemm_bf16_kernel<BM, BN, BK, WGM, WGN, RF_AMODE_CONV3X3>;
-    static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-    (void)once;
+    if (const int e = rf_enable_big_lds<gemm_bf16_kernel<BM, BN, BK, WGM, WGN, RF_AMODE_CONV3X3>>()) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(64 * WGM * WGN), lds, s, p);
   } else {
     auto k = gemm_bf16_kernel<BM, BN, BK, WGM, WGN, RF_AMODE_PLAIN>;
-    static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-    (void)once;
+    if (const int e = rf_enable_big_lds<gemm_bf16_kernel<BM, BN, BK, WGM, WGN, RF_AMODE_PLAIN>>()) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(64 * WGM * WGN), lds, s, p);
   }
   return rf_launch_status();
@@ -735,7 +733,8 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
     p.stage_epi = ok(d.N) && ok(d.c_ri) && (d.c_rc <= 0 || ok(d.c_ro)) && (d.c_cc <= 0 || (ok(d.c_cc) && ok(d.c_co))) &&
                   ok(d.c_bs[0]) && ok(d.c_bs[1]) && ok(d.c_bs[2]) && ((uintptr_t)d.C % 16) == 0 &&
                   (!d.residual || (d.c_dtype == RF_F32 && ((uintptr_t)d.residual % 16) == 0));
-    if (getenv("RF_NO_STAGED_EPILOGUE")) p.stage_epi = 0;
+    static const bool no_staged = rf_env_flag("RF_NO_STAGED_EPILOGUE");
+    if (no_staged) p.stage_epi = 0;
   }
   {
     auto p2 = [](int v) { return v <= 0 || (v & (v - 1)) == 0; };
@@ -825,7 +824,8 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   p.tilesN = (d.N + t.bn - 1) / t.bn;
   const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
   if (nblk > 0x7fffffffLL) return RF_EINVAL;
-  p.nt_store = ((int64_t)d.M * d.N * batch * (d.c_dtype == RF_F32 ? 4 : 2) > (64ll << 20)) && !getenv("RF_NO_NT_STORE");
+  static const bool no_nt_store = rf_env_flag("RF_NO_NT_STORE");
+  p.nt_store = ((int64_t)d.M * d.N * batch * (d.c_dtype == RF_F32 ? 4 : 2) > (64ll << 20)) && !no_nt_store;
   int rc = RF_EINVAL;
 #define RF_CASE(BM_, BN_, BK_, WGM_, WGN_) \
   if (t.bm == BM_ && t.bn == BN_ && t.bk == BK_) rc = launch_bf16<BM_, BN_, BK_, WGM_, WGN_>(p, nblk, s);

@@ -37,6 +37,11 @@ struct FastP {
   const float* ln_beta;
   float ln_eps;
   unsigned long long* stamps;  // timing experiments (tools/gemm_stamps.py): 8 x u64 per workgroup, else null
+  // split-C variant (CS): element (m, n) of the result goes to (m / c_rc) * c_ro + (m % c_rc) * ldc + (n / c_cc) * c_co + n % c_cc
+  // (rf_gemm_desc's C addressing; c_rc / c_cc <= 0: no split).  The q|k|v projection of the tied MSA-row attention writes
+  // its heads this way: [B, N, L, G*32] -> [B, N, G, L, 32] (csrc/tied.hip).  c_rsh / c_csh: log2 when a power of two, else -1.
+  int c_rc, c_cc, c_rsh, c_csh;
+  int64_t c_ro, c_co;
 };
 
 __device__ __forceinline__ void fast_glds16(const void* src, void* lds_wave_base) {
@@ -44,9 +49,10 @@ __device__ __forceinline__ void fast_glds16(const void* src, void* lds_wave_base
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BN, bool OUT_F32, bool HAS_RES, bool STAMP = false, bool LN = false>
+template <int BN, bool OUT_F32, bool HAS_RES, bool STAMP = false, bool LN = false, bool CS = false>
 __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
   static_assert(!LN || (OUT_F32 && HAS_RES), "the fused LayerNorm epilogue normalises the updated fp32 residual rows");
+  static_assert(!CS || (!OUT_F32 && !HAS_RES && !LN), "split-C layout: bf16 output without residual");
   constexpr int BM = 256, BK = 64, NW = 8, TM = 64, TN = BN / 2, WM = TM / 16, WN = TN / 16;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int B_INSTR = BN / 8;                  // wave-level DMA instructions per B tile (8 rows x 128 B each)
@@ -110,8 +116,18 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
     const int idx = lane + 64 * t;
     const int r = idx / CPRW, c = idx % CPRW;
     soff[t] = r * PITCHW + c * 16;
-    goff[t] = r * p.ldc + c * EPC;
+    goff[t] = CS ? ((r << 16) | (c * EPC)) : r * p.ldc + c * EPC;  // CS: (strip row, column) pair, resolved per tile
   }
+  auto cs_row = [&](int m) -> int64_t {
+    if (p.c_rc <= 0) return (int64_t)m * p.ldc;
+    const int q = p.c_rsh >= 0 ? m >> p.c_rsh : m / p.c_rc;
+    return (int64_t)q * p.c_ro + (int64_t)(m - q * p.c_rc) * p.ldc;
+  };
+  auto cs_col = [&](int n) -> int64_t {
+    if (p.c_cc <= 0) return n;
+    const int q = p.c_csh >= 0 ? n >> p.c_csh : n / p.c_cc;
+    return (int64_t)q * p.c_co + (n - q * p.c_cc);
+  };
   const float lo = p.relu ? 0.f : -INFINITY;
   constexpr int GB_OFF = 2 * STAGE_BYTES;  // LN variant: gamma | beta (BN floats each) behind the stage buffers
   if constexpr (LN) {
@@ -321,7 +337,13 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
             if (t0 + g >= NIT || !(NCH % 64 == 0 || lane + 64 * (t0 + g) < NCH)) continue;
             f32x4 v = vv[g];
             if constexpr (HAS_RES && !LN) v += res[g];
-            f32x4* dst = (f32x4*)(Cp + (unsigned)goff[t0 + g] * (unsigned)ESZ);
+            f32x4* dst;
+            if constexpr (CS) {
+              const int m = m0 + wm * TM + r0 + (goff[t0 + g] >> 16), n = n0 + wn * TN + (goff[t0 + g] & 0xffff);
+              dst = (f32x4*)((char*)p.C + (cs_row(m) + cs_col(n)) * ESZ);
+            } else {
+              dst = (f32x4*)(Cp + (unsigned)goff[t0 + g] * (unsigned)ESZ);
+            }
             if (p.nt_store)
               __builtin_nontemporal_store(v, dst);
             else
@@ -387,19 +409,13 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
   }
 }
 
-template <int BN, bool OUT_F32, bool HAS_RES, bool STAMP = false, bool LN = false>
+template <int BN, bool OUT_F32, bool HAS_RES, bool STAMP = false, bool LN = false, bool CS = false>
 static int launch_fast(const FastP& p, hipStream_t s) {
   constexpr int STAGE = (256 + BN) * 64 * 2;
-  auto k = gemm_fast_kernel<BN, OUT_F32, HAS_RES, STAMP, LN>;
-  static bool once = ((void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-  (void)once;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RF_EINVAL;
-    n_cu = prop.multiProcessorCount;
-  }
+  auto k = gemm_fast_kernel<BN, OUT_F32, HAS_RES, STAMP, LN, CS>;
+  if (const int e = rf_enable_big_lds<gemm_fast_kernel<BN, OUT_F32, HAS_RES, STAMP, LN, CS>>()) return e;
+  const int n_cu = rf_num_cus();
+  if (n_cu <= 0) return RF_EINVAL;
   const int grid = p.ntiles < n_cu ? p.ntiles : n_cu;
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), 2 * STAGE + (LN ? 2 * BN * 4 : 0), s, p);
   return rf_launch_status();
@@ -412,9 +428,14 @@ void rf_gemm_fast_set_stamps(void* buf) { g_fast_stamps = (unsigned long long*)b
 // generic kernel), a negative / HIP error code when the launch failed.
 int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream) {
   *rc = 0;
-  if (getenv("RF_NO_FAST_GEMM")) return 0;
+  static const bool no_fast = rf_env_flag("RF_NO_FAST_GEMM"), no_nt = rf_env_flag("RF_NO_NT_STORE"), no_lag = rf_env_flag("RF_GEMM_NO_LAG");
+  if (no_fast) return 0;
   if (d.ab_dtype != RF_BF16 || d.a_mode != RF_AMODE_PLAIN || batch != 1) return 0;
-  if (d.a_rc > 0 || d.b_rc > 0 || d.c_rc > 0 || d.c_cc > 0 || d.kc != d.K) return 0;
+  if (d.a_rc > 0 || d.b_rc > 0 || d.kc != d.K) return 0;
+  const bool cs = d.c_rc > 0 || d.c_cc > 0;  // split-C layout: bf16 output in whole 16-byte chunks, no residual / LayerNorm
+  if (cs && (d.c_dtype != RF_BF16 || d.residual || d.ln_out || (d.c_cc > 0 && (d.c_cc % 8 || d.c_co % 8)) ||
+             (d.c_rc > 0 && d.c_ro % 8)))
+    return 0;
   if (d.M % 256 != 0 || d.M < 16384 || d.K < 64 || d.K % 8 != 0 || d.alpha != 1.0f) return 0;
   if (d.bias_mode == RF_BIAS_ROW || (d.act != RF_ACT_NONE && d.act != RF_ACT_RELU)) return 0;
   // fused next-LayerNorm epilogue: the 288-wide pair rows (one tile spans whole rows), fp32 C with residual, no activation
@@ -441,12 +462,22 @@ int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
   const int64_t nt = (int64_t)(d.M / 256) * p.tilesN;
   if (nt > 0x7fffffffLL) return 0;
   p.ntiles = (int)nt;
-  p.nt_store = ((int64_t)d.M * d.N * (d.c_dtype == RF_F32 ? 4 : 2) > (64ll << 20)) && !getenv("RF_NO_NT_STORE");
+  p.nt_store = ((int64_t)d.M * d.N * (d.c_dtype == RF_F32 ? 4 : 2) > (64ll << 20)) && !no_nt;
   hipStream_t s = (hipStream_t)stream;
   const bool f32 = d.c_dtype == RF_F32, res = d.residual != nullptr;
   p.stamps = g_fast_stamps;
-  p.no_lag = getenv("RF_GEMM_NO_LAG") != nullptr;
+  p.no_lag = no_lag;
   p.ln_out = d.ln_out; p.ln_gamma = d.ln_gamma; p.ln_beta = d.ln_beta; p.ln_eps = d.ln_eps;
+  p.c_rc = d.c_rc; p.c_cc = d.c_cc; p.c_ro = d.c_ro; p.c_co = d.c_co;
+  p.c_rsh = (d.c_rc > 0 && (d.c_rc & (d.c_rc - 1)) == 0) ? __builtin_ctz(d.c_rc) : -1;
+  p.c_csh = (d.c_cc > 0 && (d.c_cc & (d.c_cc - 1)) == 0) ? __builtin_ctz(d.c_cc) : -1;
+  if (cs) {
+    if (bn == 288) *rc = launch_fast<288, false, false, false, false, true>(p, s);
+    else if (bn == 256) *rc = launch_fast<256, false, false, false, false, true>(p, s);
+    else if (bn == 192) *rc = launch_fast<192, false, false, false, false, true>(p, s);
+    else *rc = launch_fast<128, false, false, false, false, true>(p, s);
+    return 1;
+  }
   if (ln) {
     *rc = launch_fast<288, true, true, false, true>(p, s);
     return 1;

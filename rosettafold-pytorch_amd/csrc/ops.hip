@@ -387,7 +387,8 @@ static int launch_ln(const void* x, int x_dt, int64_t x_ld, void* y, int y_dt, i
   }
   if (!SYM && x_dt == RF_F32 && groups <= 1 && D % 4 == 0 && D >= 128 && D <= 1024 && x_ld % 4 == 0 && y_ld % 4 == 0 &&
       ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (!g || (((uintptr_t)g % 16) == 0 && ((uintptr_t)b % 16) == 0))) {
-    if ((D == 288 || D == 384) && groups <= 1 && !getenv("RF_LN_ROWS1")) {
+    static const bool ln_rows1 = rf_env_flag("RF_LN_ROWS1");
+    if ((D == 288 || D == 384) && groups <= 1 && !ln_rows1) {
       const unsigned gr = (unsigned)(rows < 65536 ? cdiv(rows, 32) : 2048);
       if (D == 288)
         hipLaunchKernelGGL((layernorm_rows8_kernel<9>), dim3(gr), dim3(256), 0, s, (const float*)x, x_ld, y, y_dt, y_ld, rows, g, b, eps, act);
@@ -634,7 +635,7 @@ extern "C" int rf_weighted_msa_sum(const void* x, int dtype, const float* w, flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// InstanceNorm over NHWC: statistics (fp64 atomics of per-block fp32 partials) + apply
+// InstanceNorm over NHWC: statistics (per-block fp32 partials reduced in block order in fp64: no atomics) + apply
 // ------------------------------------------------------------------------------------------------
 #define IN_PIX 128  // pixels per block
 __global__ void instnorm_finalize_kernel(const float* partials, double* sums, int nblk, int C);
@@ -650,14 +651,9 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const void* x, int 
       s += v;
       q = fmaf(v, v, q);
     }
-    if (partials) {  // deterministic path (see instnorm_finalize_kernel)
-      float* pp = partials + ((int64_t)b * gridDim.x + blockIdx.x) * 2 * C;
-      pp[c] = s;
-      pp[C + c] = q;
-    } else {
-      atomicAdd(&sums[((int64_t)b * C + c) * 2 + 0], (double)s);
-      atomicAdd(&sums[((int64_t)b * C + c) * 2 + 1], (double)q);
-    }
+    float* pp = partials + ((int64_t)b * gridDim.x + blockIdx.x) * 2 * C;  // reduced by instnorm_finalize_kernel
+    pp[c] = s;
+    pp[C + c] = q;
   }
 }
 
@@ -704,10 +700,7 @@ __global__ __launch_bounds__(256) void instnorm_stats_vec_kernel(const bf16_t* x
   for (int c = threadIdx.x; c < 2 * C; c += 256) {  // c < C: sum, c >= C: sum of squares
     float t = 0.f;
     for (int g = 0; g < ppi; ++g) t += sm[g * 2 * C + c];
-    if (partials)  // deterministic path: per-block partials, reduced in block order by instnorm_finalize_kernel
-      partials[((int64_t)b * gridDim.x + blockIdx.x) * 2 * C + c] = t;
-    else
-      atomicAdd(&sums[((int64_t)b * C + (c < C ? c : c - C)) * 2 + (c < C ? 0 : 1)], (double)t);
+    partials[((int64_t)b * gridDim.x + blockIdx.x) * 2 * C + c] = t;  // reduced in block order by instnorm_finalize_kernel
   }
 }
 
@@ -780,27 +773,24 @@ extern "C" int64_t rf_instnorm_ws_bytes(int B, int64_t HW, int C) {
 extern "C" int rf_instnorm_stats(const void* x, int x_dtype, void* sums, int B, int64_t HW, int C, void* workspace,
                                  int64_t ws_bytes, void* stream) {
   RF_CHECK_DT(x_dtype);
+  // the workspace (rf_instnorm_ws_bytes) is mandatory: the library has no atomic-accumulation path, so results are
+  // bitwise reproducible run to run
+  if (!workspace || ws_bytes < rf_instnorm_ws_bytes(B, HW, C)) return RF_EINVAL;
+  float* partials = (float*)workspace;
   if (x_dtype == RF_BF16 && C % 8 == 0 && C / 8 <= 256 && ((uintptr_t)x % 16) == 0) {
     const unsigned nblk = cdiv(HW, INV_PIX);
     const int ppi = 256 / (C / 8);
-    // with a workspace of rf_instnorm_ws_bytes(B, HW, C) the reduction is free of atomics and bitwise reproducible
-    float* partials = (workspace && ws_bytes >= (int64_t)B * nblk * 2 * C * (int64_t)sizeof(float)) ? (float*)workspace : nullptr;
     hipLaunchKernelGGL(instnorm_stats_vec_kernel, dim3(nblk, B), dim3(256), (size_t)ppi * 2 * C * sizeof(float),
                        (hipStream_t)stream, (const bf16_t*)x, (double*)sums, partials, HW, C);
-    if (partials)
-      hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(2 * C, 256), B), dim3(256), 0, (hipStream_t)stream, partials,
-                         (double*)sums, (int)nblk, C);
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(2 * C, 256), B), dim3(256), 0, (hipStream_t)stream, partials,
+                       (double*)sums, (int)nblk, C);
     return rf_launch_status();
   }
-  {
-    const unsigned nblk = cdiv(HW, IN_PIX);
-    float* partials = (workspace && ws_bytes >= (int64_t)B * nblk * 2 * C * (int64_t)sizeof(float)) ? (float*)workspace : nullptr;
-    hipLaunchKernelGGL(instnorm_stats_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, x, x_dtype, (double*)sums,
-                       partials, HW, C);
-    if (partials)
-      hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(2 * C, 256), B), dim3(256), 0, (hipStream_t)stream, partials,
-                         (double*)sums, (int)nblk, C);
-  }
+  const unsigned nblk = cdiv(HW, IN_PIX);
+  hipLaunchKernelGGL(instnorm_stats_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, x, x_dtype, (double*)sums,
+                     partials, HW, C);
+  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(2 * C, 256), B), dim3(256), 0, (hipStream_t)stream, partials,
+                     (double*)sums, (int)nblk, C);
   return rf_launch_status();
 }
 
@@ -1208,19 +1198,150 @@ extern "C" int rf_dist_masked_attention(const float* q, const float* k, const fl
   return rf_launch_status();
 }
 
-// x[r, :] *= w[r]
-__global__ __launch_bounds__(256) void scale_rows_kernel(void* x, int dt, const float* w, int64_t total, int D) {
+// y[r, :] = x[r, :] * w[r]   (y may alias x)
+__global__ __launch_bounds__(256) void scale_rows_kernel(const void* x, void* y, int dt, const float* w, int64_t total, int D) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256)
-    st(x, dt, e, ld(x, dt, e) * w[e / D]);
+    st(y, dt, e, ld(x, dt, e) * w[e / D]);
 }
 
-extern "C" int rf_scale_rows(void* x, int dtype, const float* w, int64_t rows, int D, void* stream) {
+extern "C" int rf_scale_rows(const void* x, void* y, int dtype, const float* w, int64_t rows, int D, void* stream) {
   RF_CHECK_DT(dtype);
   const int64_t total = rows * D;
-  hipLaunchKernelGGL(scale_rows_kernel, dim3(min(cdiv(total, 256), 32768u)), dim3(256), 0, (hipStream_t)stream, x,
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(min(cdiv(total, 256), 32768u)), dim3(256), 0, (hipStream_t)stream, x, y,
                      dtype, w, total, D);
   return rf_launch_status();
 }
 
-extern "C" int rf_version(void) { return 1; }
-extern "C" const char* rf_build_info(void) { return "librfmi gfx950 (MI355X) round-1"; }
+// ------------------------------------------------------------------------------------------------
+// small helpers that keep ATen kernels off the forward path: fill, input validation, one-hot, sequence-separation
+// feature, stand-alone positional encodings
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fill_kernel(void* y, int dt, float v, int64_t n) {
+  const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  if (dt == RF_F32) {
+    float4* y4 = (float4*)y;
+    const int64_t n4 = n >> 2;
+    for (int64_t e = t0; e < n4; e += stride) y4[e] = make_float4(v, v, v, v);
+    for (int64_t e = (n4 << 2) + t0; e < n; e += stride) ((float*)y)[e] = v;
+  } else {
+    const unsigned h = f2bf(v), w = h | (h << 16);
+    uint4* y8 = (uint4*)y;
+    const int64_t n8 = n >> 3;
+    for (int64_t e = t0; e < n8; e += stride) y8[e] = make_uint4(w, w, w, w);
+    for (int64_t e = (n8 << 3) + t0; e < n; e += stride) ((bf16_t*)y)[e] = (bf16_t)h;
+  }
+}
+
+extern "C" int rf_fill(void* y, int dtype, float value, int64_t n, void* stream) {
+  RF_CHECK_DT(dtype);
+  if (n <= 0) return 0;
+  if ((uintptr_t)y % 16) return RF_EALIGN;
+  hipLaunchKernelGGL(fill_kernel, dim3(min(cdiv(n, 256 * 8), 8192u)), dim3(256), 0, (hipStream_t)stream, y, dtype, value, n);
+  return rf_launch_status();
+}
+
+// flags[0] = 1 if a token is outside [0, d_input); flags[1] = 1 if an aa_idx is outside [0, max_len); flags[2] = 1 if
+// aa_idx is not strictly increasing along a sample.  Plain idempotent stores (every writer stores 1): no atomics.
+// flags must be zeroed by the caller.
+__global__ __launch_bounds__(256) void check_inputs_kernel(const int64_t* msa, int64_t n_msa, const int64_t* seq, int64_t n_seq,
+                                                           const int64_t* aa_idx, int64_t n_idx, int L, int d_input,
+                                                           int max_len, int32_t* flags) {
+  const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+  bool bad_tok = false, bad_idx = false, not_mono = false;
+  for (int64_t e = t0; e < n_msa; e += stride) bad_tok |= msa[e] < 0 || msa[e] >= d_input;
+  for (int64_t e = t0; e < n_seq; e += stride) bad_tok |= seq[e] < 0 || seq[e] >= d_input;
+  for (int64_t e = t0; e < n_idx; e += stride) {
+    const int64_t v = aa_idx[e];
+    bad_idx |= v < 0 || v >= max_len;
+    if (e % L) not_mono |= aa_idx[e - 1] >= v;
+  }
+  if (bad_tok) flags[0] = 1;
+  if (bad_idx) flags[1] = 1;
+  if (not_mono) flags[2] = 1;
+}
+
+extern "C" int rf_check_inputs(const int64_t* msa, int64_t n_msa, const int64_t* seq, int64_t n_seq, const int64_t* aa_idx,
+                               int64_t n_idx, int L, int d_input, int max_len, int32_t* flags, void* stream) {
+  if (!flags || L <= 0) return RF_EINVAL;
+  if (!msa) n_msa = 0;
+  if (!seq) n_seq = 0;
+  if (!aa_idx) n_idx = 0;
+  const int64_t n = n_msa > n_idx ? (n_msa > n_seq ? n_msa : n_seq) : (n_idx > n_seq ? n_idx : n_seq);
+  hipLaunchKernelGGL(check_inputs_kernel, dim3(min(cdiv(n > 0 ? n : 1, 256), 1024u)), dim3(256), 0, (hipStream_t)stream,
+                     msa, n_msa, seq, n_seq, aa_idx, n_idx, L, d_input, max_len, flags);
+  return rf_launch_status();
+}
+
+// y[r, col0 + c] = (idx[r] == c) for c < n_classes   (F.one_hot(seq, 21), rf.py:1276)
+__global__ __launch_bounds__(256) void onehot_kernel(const int64_t* idx, void* y, int dt, int64_t ld_, int col0, int nc,
+                                                     int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / nc;
+    const int c = e % nc;
+    st(y, dt, r * ld_ + col0 + c, idx[r] == c ? 1.f : 0.f);
+  }
+}
+
+extern "C" int rf_onehot(const int64_t* idx, void* y, int dtype, int64_t y_ld, int col0, int n_classes, int64_t rows,
+                         void* stream) {
+  RF_CHECK_DT(dtype);
+  const int64_t total = rows * n_classes;
+  if (total <= 0) return RF_EINVAL;
+  hipLaunchKernelGGL(onehot_kernel, dim3(min(cdiv(total, 256), 4096u)), dim3(256), 0, (hipStream_t)stream, idx, y, dtype, y_ld,
+                     col0, n_classes, total);
+  return rf_launch_status();
+}
+
+// y[(b,i,j), col] = clamp(sign(d) * log(|d| + 1), 0, 5.5), d = idx[b,i] - idx[b,j]   (rf.py:746-749: signed, then clamped >= 0)
+__global__ __launch_bounds__(256) void seqsep_kernel(const int64_t* aa_idx, void* y, int dt, int64_t ld_, int col, int L,
+                                                     int64_t total) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int j = e % L, i = (e / L) % L;
+    const int64_t b = e / ((int64_t)L * L);
+    const int64_t d = aa_idx[b * L + i] - aa_idx[b * L + j];
+    const float v = d > 0 ? fminf(logf((float)(d + 1)), 5.5f) : 0.f;
+    st(y, dt, e * ld_ + col, v);
+  }
+}
+
+extern "C" int rf_seqsep_feature(const int64_t* aa_idx, void* y, int dtype, int64_t y_ld, int col, int B, int L, void* stream) {
+  RF_CHECK_DT(dtype);
+  const int64_t total = (int64_t)B * L * L;
+  if (total <= 0) return RF_EINVAL;
+  hipLaunchKernelGGL(seqsep_kernel, dim3(min(cdiv(total, 256), 4096u)), dim3(256), 0, (hipStream_t)stream, aa_idx, y, dtype,
+                     y_ld, col, L, total);
+  return rf_launch_status();
+}
+
+// Stand-alone positional encodings (rf.py:72-76 and rf.py:95-103):
+//   two_d == 0: y[b,n,l,:] = x[b,n,l,:] + pe[aa_idx[b,l], :]                      (x: [B, N, L, D], pe: [max_len, D])
+//   two_d != 0: y[b,i,j,:] = x[b,i,j,:] + [pe[aa_idx[b,i]] | pe[aa_idx[b,j]]]      (x: [B, L, L, D], N == L, pe: [max_len, D/2])
+__global__ __launch_bounds__(256) void add_pos_enc_kernel(const float* x, const int64_t* aa_idx, const float* pe, float* y,
+                                                          int N, int L, int D, int two_d, int64_t total) {
+  const int dh = D / 2;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int c = e % D;
+    const int64_t r = e / D;
+    const int l = r % L, n = (r / L) % N;
+    const int64_t b = r / ((int64_t)L * N);
+    float p;
+    if (two_d)
+      p = c < dh ? pe[aa_idx[b * L + n] * dh + c] : pe[aa_idx[b * L + l] * dh + (c - dh)];
+    else
+      p = pe[aa_idx[b * L + l] * D + c];
+    y[e] = x[e] + p;
+  }
+}
+
+extern "C" int rf_add_pos_enc(const float* x, const int64_t* aa_idx, const float* pe, float* y, int B, int N, int L, int D,
+                              int two_d, void* stream) {
+  if (two_d && (N != L || D % 2)) return RF_EINVAL;
+  const int64_t total = (int64_t)B * N * L * D;
+  if (total <= 0) return RF_EINVAL;
+  hipLaunchKernelGGL(add_pos_enc_kernel, dim3(min(cdiv(total, 256), 16384u)), dim3(256), 0, (hipStream_t)stream, x, aa_idx, pe,
+                     y, N, L, D, two_d, total);
+  return rf_launch_status();
+}
+
+extern "C" int rf_version(void) { return 2; }
+extern "C" const char* rf_build_info(void) { return "librfmi gfx950 (MI355X) round-2"; }

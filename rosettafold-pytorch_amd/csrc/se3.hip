@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void knn_mask_kernel(const float* xyz, const i
       const float dt = dist[t];
       rank += (dt < dj || (dt == dj && t < j)) ? 1 : 0;
     }
+    if (!(dj == dj)) rank = L;  // NaN distance: every comparison is false -> it would rank first; never a neighbour
     const int64_t jj = aa_idx[(int64_t)b * L + j];
     const int64_t sep = ii > jj ? ii - jj : jj - ii;
     const bool near = (j != i) && sep < kmin;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void edge_count_kernel(const uint8_t* mask, in
 }
 
 __global__ __launch_bounds__(256) void edge_scan_kernel(const int32_t* row_cnt, int32_t* row_off, int32_t* count,
-                                                        int rows) {
+                                                        int rows, int64_t capacity) {
   // single block exclusive scan (rows <= a few thousand)
   __shared__ int part[256];
   const int per = (rows + 255) / 256;
@@ -77,7 +78,8 @@ __global__ __launch_bounds__(256) void edge_scan_kernel(const int32_t* row_cnt, 
       part[t] = run;
       run += v;
     }
-    count[0] = run;
+    count[0] = run < capacity ? run : (int32_t)capacity;  // consumers walk [0, count[0]): never past the buffers
+    count[1] = run;                                         // true edge count (> capacity: overflow, edges were dropped)
   }
   __syncthreads();
   int run = part[threadIdx.x];
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void edge_scan_kernel(const int32_t* row_cnt, 
 }
 
 __global__ __launch_bounds__(256) void edge_write_kernel(const uint8_t* mask, const int32_t* row_off, int32_t* src,
-                                                         int32_t* dst, int32_t* eid, int L) {
+                                                         int32_t* dst, int32_t* eid, int L, int64_t capacity) {
   __shared__ int wsum[4];
   __shared__ int base;
   const int row = blockIdx.x;  // b*L + i
@@ -109,8 +111,12 @@ __global__ __launch_bounds__(256) void edge_write_kernel(const uint8_t* mask, co
       int id = -1;
       if (m) {
         id = off + before;
-        src[id] = row;
-        dst[id] = b * L + j;
+        if (id < capacity) {
+          src[id] = row;
+          dst[id] = b * L + j;
+        } else {
+          id = -1;  // beyond the caller's buffers: dropped (count[1] > capacity reports it)
+        }
       }
       eid[(int64_t)row * L + j] = id;
     }
@@ -121,14 +127,15 @@ __global__ __launch_bounds__(256) void edge_write_kernel(const uint8_t* mask, co
 }
 
 extern "C" int rf_edges_from_mask(const uint8_t* mask, int32_t* src, int32_t* dst, int32_t* eid, int32_t* count,
-                                  int32_t* row_ws, int B, int L, void* stream) {
+                                  int32_t* row_ws, int B, int L, int64_t capacity, void* stream) {
+  if (capacity <= 0 || capacity > 0x7fffffffLL) return RF_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int rows = B * L;
   int32_t* row_cnt = row_ws;
   int32_t* row_off = row_ws + rows;
   hipLaunchKernelGGL(edge_count_kernel, dim3(rows), dim3(256), 0, s, mask, row_cnt, L);
-  hipLaunchKernelGGL(edge_scan_kernel, dim3(1), dim3(256), 0, s, row_cnt, row_off, count, rows);
-  hipLaunchKernelGGL(edge_write_kernel, dim3(rows), dim3(256), 0, s, mask, row_off, src, dst, eid, L);
+  hipLaunchKernelGGL(edge_scan_kernel, dim3(1), dim3(256), 0, s, row_cnt, row_off, count, rows, capacity);
+  hipLaunchKernelGGL(edge_write_kernel, dim3(rows), dim3(256), 0, s, mask, row_off, src, dst, eid, L, capacity);
   return rf_launch_status();
 }
 
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(256) void se3_attention_kernel(const float* k0, con
                                                             const float* q1, const float* v0, const float* v1,
                                                             const int32_t* eid, float* out0, float* out1, int heads,
                                                             int mk0, int mk1, int mv0, int mv1, int V, int L,
-                                                            float inv_sqrt_nfeat) {
+                                                            float inv_sqrt_nfeat, int64_t o0_ld, int64_t o1_ld) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wid >= (int64_t)V * heads) return;
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(256) void se3_attention_kernel(const float* k0, con
     for (int t = 0; t < RF_ATT_MAXPL; ++t)
       if (ids[t] >= 0) a = fmaf(lg[t], v0[(int64_t)ids[t] * mv0 + hd * cv0 + c], a);
     a = wave_sum(a);
-    if (lane == 0) out0[(int64_t)node * mv0 + hd * cv0 + c] = a * inv;
+    if (lane == 0) out0[(int64_t)node * o0_ld + hd * cv0 + c] = a * inv;
   }
   for (int c = 0; c < cv1 * 3; ++c) {
     float a = 0.f;
@@ -335,17 +342,20 @@ __global__ __launch_bounds__(256) void se3_attention_kernel(const float* k0, con
     for (int t = 0; t < RF_ATT_MAXPL; ++t)
       if (ids[t] >= 0) a = fmaf(lg[t], v1[((int64_t)ids[t] * mv1 + hd * cv1) * 3 + c], a);
     a = wave_sum(a);
-    if (lane == 0) out1[((int64_t)node * mv1 + hd * cv1) * 3 + c] = a * inv;
+    if (lane == 0) out1[(int64_t)node * o1_ld + hd * cv1 * 3 + c] = a * inv;
   }
 }
 
 extern "C" int rf_se3_attention(const float* k0, const float* k1, const float* q0, const float* q1, const float* v0,
                                 const float* v1, const int32_t* eid, float* out0, float* out1, int heads, int mk0,
-                                int mk1, int mv0, int mv1, int V, int L, void* stream) {
+                                int mk1, int mv0, int mv1, int V, int L, int64_t out0_ld, int64_t out1_ld, void* stream) {
   if (L > 64 * RF_ATT_MAXPL) return RF_EINVAL;
+  if (out0_ld <= 0) out0_ld = mv0;      // elements per node row of out0 / out1 (> mv0 / 3*mv1: the attention writes the
+  if (out1_ld <= 0) out1_ld = 3 * mv1;  // leading channels of the GCat buffer, ea/modules.py:903-928)
+  if (out0_ld < mv0 || out1_ld < 3 * mv1) return RF_EINVAL;
   const float nfeat = (float)(mk0 + 3 * mk1);
   hipLaunchKernelGGL(se3_attention_kernel, dim3(cdiv((int64_t)V * heads, 4)), dim3(256), 0, (hipStream_t)stream, k0, k1,
-                     q0, q1, v0, v1, eid, out0, out1, heads, mk0, mk1, mv0, mv1, V, L, 1.0f / sqrtf(nfeat));
+                     q0, q1, v0, v1, eid, out0, out1, heads, mk0, mk1, mv0, mv1, V, L, 1.0f / sqrtf(nfeat), out0_ld, out1_ld);
   return rf_launch_status();
 }
 

@@ -36,6 +36,7 @@ class _Runtime:
     fused_favor = True  # use the fused FAVOR+ kernel when the shape allows (bf16, dim_head 64, seq 128/256)
     fused_outer_ln = not bool(int(__import__("os").environ.get("RF_NO_FUSED_OUTER_LN", "0")))  # LayerNorm(1024) in the outer-product GEMM epilogue
     fused_tied = not bool(int(__import__("os").environ.get("RF_NO_FUSED_TIED", "0")))  # tied-attention logits + softmax in one launch
+    tied_v2 = not bool(int(__import__("os").environ.get("RF_TIED_V1", "0")))  # head-major q|k|v + collapsed weights + A.V kernel
     head_major_qkv = bool(int(__import__("os").environ.get("RF_HEAD_MAJOR_QKV", "0")))
     # Producer -> consumer chains whose intermediate (q|k|v, feed-forward hidden) is larger than this many bytes are run
     # panel by panel, so the intermediate panel is still in the 256 MB Infinity Cache when its consumer reads it
@@ -75,20 +76,50 @@ def pad8(n):
     return (n + 7) // 8 * 8
 
 
+def weights_fingerprint(module):
+    """Changes whenever a parameter / buffer of `module` is rebound, moved or edited in place (p.copy_, nn.init.*,
+    optimizer steps bump `_version`; `.data = ...`, `.to()` change `data_ptr`)."""
+    h = 0
+    for t in list(module.parameters()) + list(module.buffers()):
+        h = (h * 1000003 + t.data_ptr() + 7919 * t._version) & 0xFFFFFFFFFFFFFFF
+    return h
+
+
+def invalidate_weight_caches(module):
+    """Drop every kernel-ready weight copy held below `module` (they are rebuilt on the next call)."""
+    for m in module.modules():
+        c = getattr(m, "_rfc", None)
+        if isinstance(c, dict):
+            c.clear()
+        elif c is not None:
+            object.__setattr__(m, "_rfc", None)
+
+
 class RFModule(nn.Module):
-    """nn.Module with a cache of kernel-ready weights (cast / concatenated / padded)."""
+    """nn.Module with a cache of kernel-ready weights (cast / concatenated / padded).  The cache is validated against the
+    live parameters at every PUBLIC call (`module(...)`): internal composition goes through `.run()` / `.attend()`, so
+    the check costs one pass over the parameter list per user-level call, not per kernel."""
 
     def __init__(self):
         super().__init__()
         object.__setattr__(self, "_rfc", {})
+        object.__setattr__(self, "_rf_fp", None)
 
     def _apply(self, fn, *a, **k):
-        self._rfc.clear()
+        invalidate_weight_caches(self)
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):
         self._rfc.clear()
         return super()._load_from_state_dict(*a, **k)
+
+    def __call__(self, *a, **k):
+        fp = weights_fingerprint(self)
+        if fp != self._rf_fp:
+            if self._rf_fp is not None:
+                invalidate_weight_caches(self)
+            object.__setattr__(self, "_rf_fp", fp)
+        return super().__call__(*a, **k)
 
     def cached(self, key, fn):
         k = (key, RT.dtype)
@@ -119,6 +150,27 @@ def _f(p):
     return None if p is None else p.detach()
 
 
+def fresh_f32(x):
+    """A new contiguous fp32 copy of x (the public forwards never mutate their inputs)."""
+    y = torch.empty(x.shape, device=x.device, dtype=F32)
+    return ops.axpby(x.detach().contiguous(), 1.0, None, 0.0, y)
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm as a parameter container (same state_dict keys); a direct call runs rf_layernorm, not ATen."""
+
+    def forward(self, x):
+        return ops.layernorm(x.contiguous(), _f(self.weight), _f(self.bias), eps=self.eps, out_dtype=F32)
+
+
+class Linear(nn.Linear):
+    """nn.Linear as a parameter container; a direct call runs rf_gemm in the current compute dtype (fp32 result)."""
+
+    def forward(self, x):
+        xt = ops.cast(x.contiguous(), T())
+        return ops.linear(xt, ops.cast(self.weight.detach().contiguous(), T()), _f(self.bias), out_dtype=F32)
+
+
 def ln(mod, x, out_dtype=None, **kw):
     return ops.layernorm(x, _f(mod.weight), _f(mod.bias), eps=mod.eps, out_dtype=out_dtype or T(), **kw)
 
@@ -127,11 +179,57 @@ def ln(mod, x, out_dtype=None, **kw):
 # small building blocks
 # ================================================================================================
 class Residual(nn.Module):
-    """rf.py:18-28 -- parameter container only (keeps the reference's `fn` naming)."""
+    """rf.py:18-28: fn(x) + x (dropout is the identity at inference).  The model's own compositions fuse the residual
+    add into the producing GEMM's epilogue; this forward serves a directly called / user-wrapped module."""
 
     def __init__(self, fn, p_dropout=None):
         super().__init__()
         self.fn = fn
+
+    def forward(self, x):
+        fx = self.fn(x)
+        if isinstance(fx, tuple):
+            raise TypeError("Residual wraps modules that return one tensor")
+        out = torch.empty(x.shape, device=x.device, dtype=F32)
+        return ops.axpby(fx.contiguous(), 1.0, x.contiguous(), 1.0, out)
+
+
+class ColWise(nn.Module):
+    """rf.py:31-41: fn over the sequences x[b, n, :, :] (attention along dim 2)."""
+
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, x):
+        b, n, l, d = x.shape
+        if isinstance(self.fn, PerformerSelfAttention):  # strided addressing inside the kernels: no reshape
+            out = ops.zeros(b, n, l, d, device=x.device, dtype=F32)
+            self.fn.attend(ops.cast(x.contiguous(), T()), out, axis=2)
+            return out
+        return self.fn(x.reshape(b * n, l, d)).reshape(b, n, l, -1)
+
+
+class RowWise(nn.Module):
+    """rf.py:44-54: fn over the sequences x[b, :, l, :] (attention along dim 1)."""
+
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, x):
+        b, n, l, d = x.shape
+        if isinstance(self.fn, PerformerSelfAttention):
+            out = ops.zeros(b, n, l, d, device=x.device, dtype=F32)
+            self.fn.attend(ops.cast(x.contiguous(), T()), out, axis=1)
+            return out
+        xt = torch.empty(b, l, n, d, device=x.device, dtype=x.dtype)
+        ops.copy4d(x.contiguous(), (n * l * d, d, l * d, 1), xt, (l * n * d, n * d, d, 1), (b, l, n, d))
+        y = self.fn(xt.view(b * l, n, d)).contiguous()
+        do = y.shape[-1]
+        out = torch.empty(b, n, l, do, device=x.device, dtype=y.dtype)
+        ops.copy4d(y, (l * n * do, n * do, do, 1), out, (n * l * do, do, l * do, 1), (b, l, n, do))
+        return out
 
 
 class FeedForward(RFModule):
@@ -139,7 +237,7 @@ class FeedForward(RFModule):
 
     def __init__(self, d_emb, d_ff, p_dropout=0.1):
         super().__init__()
-        self.net = nn.Sequential(nn.Linear(d_emb, d_ff), nn.ReLU(), nn.Dropout(p_dropout), nn.Linear(d_ff, d_emb))
+        self.net = nn.Sequential(Linear(d_emb, d_ff), nn.ReLU(), nn.Dropout(p_dropout), Linear(d_ff, d_emb))
 
     def apply_residual(self, xn, x_res, next_ln=None):
         """x_res += W2 relu(W1 xn + b1) + b2   (x_res fp32, in place).  With `next_ln` the second GEMM's epilogue also
@@ -159,7 +257,7 @@ class FeedForward(RFModule):
 
     def forward(self, x):
         xn = ops.cast(x.contiguous(), T())
-        out = torch.zeros(x.shape, device=x.device, dtype=F32)
+        out = ops.zeros(*x.shape, device=x.device, dtype=F32)
         self.apply_residual(xn, out)
         return out
 
@@ -174,6 +272,18 @@ def sinusoid_table(dim, max_len):
     return pe
 
 
+def check_index_range(msa, seq, aa_idx, d_input, max_len):
+    """The reference raises IndexError from nn.Embedding / table indexing (rf.py:73,98,115-119,155) for a token outside
+    [0, d_input) or a residue index outside [0, max_len); the kernels index unchecked, so the wrappers validate first
+    (one small launch + one 12-byte read-back).  Returns whether aa_idx is strictly increasing inside every sample."""
+    bad_tok, bad_idx, not_mono = ops.check_inputs(msa, seq, aa_idx, d_input, max_len)
+    if bad_tok:
+        raise IndexError(f"token index out of range [0, {d_input})")
+    if bad_idx:
+        raise IndexError(f"aa_idx out of range [0, {max_len}) (max_len of the positional-encoding table)")
+    return not not_mono
+
+
 class SinusoidalPositionalEncoding(RFModule):
     """rf.py:57-76."""
 
@@ -181,6 +291,12 @@ class SinusoidalPositionalEncoding(RFModule):
         super().__init__()
         self.dim, self.max_len = dim, max_len
         self.register_buffer("pos_enc", sinusoid_table(dim, max_len), persistent=False)
+
+    def forward(self, x, aa_idx):
+        """x [B,N,L,dim] + pos_enc[aa_idx] broadcast over N (rf.py:72-76; dropout = identity)."""
+        aa_idx = aa_idx.to(x.device).contiguous()
+        check_index_range(None, None, aa_idx, 1, self.max_len)
+        return ops.add_pos_enc(x.float().contiguous(), aa_idx, self.pos_enc, two_d=False)
 
 
 class SinusoidalPositionalEncoding2D(RFModule):
@@ -190,6 +306,12 @@ class SinusoidalPositionalEncoding2D(RFModule):
         super().__init__()
         self.max_len = max_len
         self.register_buffer("pos_enc", sinusoid_table(dim // 2, max_len), persistent=False)
+
+    def forward(self, x, aa_idx):
+        """x [B,L,L,dim] + [pos_enc[idx_i] | pos_enc[idx_j]] (rf.py:95-103)."""
+        aa_idx = aa_idx.to(x.device).contiguous()
+        check_index_range(None, None, aa_idx, 1, self.max_len)
+        return ops.add_pos_enc(x.float().contiguous(), aa_idx, self.pos_enc, two_d=True)
 
 
 class MsaEmbedding(RFModule):
@@ -202,6 +324,11 @@ class MsaEmbedding(RFModule):
         self.query_enc = nn.Embedding(2, d_msa)
 
     def forward(self, x, aa_idx):
+        check_index_range(x.contiguous(), None, aa_idx.contiguous(), self.to_embedding.num_embeddings, self.pos_enc.max_len)
+        return self.run(x, aa_idx)
+
+    def run(self, x, aa_idx):
+        """(indices already validated)"""
         return ops.msa_embed(x.contiguous(), aa_idx.contiguous(), _f(self.to_embedding.weight), self.pos_enc.pos_enc,
                              _f(self.query_enc.weight))
 
@@ -217,11 +344,16 @@ class PairEmbedding(RFModule):
         self.use_template = use_template
         if use_template:
             raise NotImplementedError("template branch (rf.py:141-169) is outside the forward path (SURVEY 8(f))")
-        self.proj = nn.Linear(d_pair + 1, d_pair)
+        self.proj = Linear(d_pair + 1, d_pair)
 
     def forward(self, seq, aa_idx, template=None):
         if template is not None:
             raise ValueError(f"[{self.__class__.__name__}]: template is not None but use_template is False")
+        check_index_range(None, seq.contiguous(), aa_idx.contiguous(), self.embed_seq.num_embeddings, self.pos_enc.max_len)
+        return self.run(seq, aa_idx)
+
+    def run(self, seq, aa_idx):
+        """(indices already validated)"""
         h = self.half_d_pair
 
         def tables():
@@ -248,8 +380,8 @@ class PositionWiseWeightFactor(RFModule):
         self.n_heads = n_heads
         self.d_head = d_msa // n_heads
         self.scale = self.d_head ** (-0.5)
-        self.to_q = nn.Sequential(nn.Linear(d_msa, d_msa), nn.Identity())
-        self.to_k = nn.Sequential(nn.Linear(d_msa, d_msa), nn.Identity())
+        self.to_q = nn.Sequential(Linear(d_msa, d_msa), nn.Identity())
+        self.to_k = nn.Sequential(Linear(d_msa, d_msa), nn.Identity())
 
     def query_proj(self, xn):
         """to_q on MSA row 0 only: [B*L, d] (T)."""
@@ -298,10 +430,10 @@ class SoftTiedAttentionOverResidues(RFModule):
         self.scale = self.d_head ** (-0.5)
         self.return_att = return_att
         self.poswise_weight = PositionWiseWeightFactor(d_msa, n_heads, p_dropout)
-        self.to_q = nn.Linear(d_msa, d_msa)
-        self.to_k = nn.Linear(d_msa, d_msa)
-        self.to_v = nn.Linear(d_msa, d_msa)
-        self.to_out = nn.Linear(d_msa, d_msa)
+        self.to_q = Linear(d_msa, d_msa)
+        self.to_k = Linear(d_msa, d_msa)
+        self.to_v = Linear(d_msa, d_msa)
+        self.to_out = Linear(d_msa, d_msa)
 
     def attend(self, xn, x_res, want_att, next_ln=None):
         """xn: T [B,N,L,D] (already layer-normed); x_res: fp32 [B,N,L,D] += to_out(attention).  Returns
@@ -310,6 +442,10 @@ class SoftTiedAttentionOverResidues(RFModule):
         H, dh = self.n_heads, self.d_head
         dev = xn.device
         pw = self.poswise_weight
+        if (RT.fused_tied and RT.tied_v2 and T() == torch.bfloat16 and dh == 32 and Lr in (64, 128, 192, 256) and H <= 16
+                and N % 16 == 0 and N // 16 in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16) and (B * N * Lr) % 256 == 0 and B * N * Lr >= 16384
+                and (6 if Lr >= 256 else 8) * (4096 + Lr * 64) + 1024 + N * 256 <= 160 * 1024):
+            return self.attend_head_major(xn, x_res, want_att, next_ln)
         # one GEMM for q | k | poswise-k  (N = 3D)
         wcat = self.wcat("qkp", [self.to_q, self.to_k, pw.to_k[0]])
         bcat = self.bcat("qkp", [self.to_q, self.to_k, pw.to_k[0]])
@@ -344,9 +480,38 @@ class SoftTiedAttentionOverResidues(RFModule):
         xn_next = ops.linear_residual_ln(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln)
         return att_sym, xn_next
 
+    def attend_head_major(self, xn, x_res, want_att, next_ln=None):
+        """The bench path (csrc/tied.hip): one projection GEMM writes q|k|v head-major [B,N,3H,L,32] (every contraction
+        step of the attention kernels is then one contiguous tile), the position weights come from the collapsed form
+        (no to_k projection over the N rows) and are applied inside the logits kernel, attention.V consumes v with
+        transposed LDS reads: no v^T GEMM, no pass over q, no fp32 logits."""
+        B, N, Lr, D = xn.shape
+        H, dh = self.n_heads, self.d_head
+        dev = xn.device
+        pw = self.poswise_weight
+        G = 3 * H
+        lins = [self.to_q, self.to_k, self.to_v]
+        qkv = torch.empty(B, N, G, Lr, dh, device=dev, dtype=T())
+        ops.gemm(xn, self.wcat("qkv", lins), qkv, B * N * Lr, 3 * D, D, bias=self.bcat("qkv", lins),
+                 c_row=(Lr, G * Lr * dh, dh), c_col=(dh, Lr * dh))
+        # u[b,l,h,:] = W_k[h*dh:(h+1)*dh, :]^T to_q(x_0)[b,l,h*dh:(h+1)*dh]   (rf.py:205-217, collapsed)
+        q0 = pw.query_proj(xn)
+        wkt = pw.cached("wkT", lambda: pw.to_k[0].weight.detach().t().contiguous().to(T()))
+        u = torch.empty(B, Lr, H, D, device=dev, dtype=T())
+        ops.gemm(q0, wkt, u, B * Lr, D, dh, batch=(H, 1, 1), a_bs=(dh, 0, 0), a_row=(0, 0, D), b_bs=(dh, 0, 0),
+                 b_row=(0, 0, D), c_bs=(D, 0, 0), c_row=(0, 0, H * D))
+        w = ops.poswise_collapsed(xn, u, pw.scale)  # fp32 [B,H,N,L]
+        att = torch.empty(B, H, Lr, Lr, device=dev, dtype=T())
+        att_sym = torch.empty(B, Lr, Lr, H, device=dev, dtype=F32) if want_att else None
+        out = torch.empty(B, N, Lr, D, device=dev, dtype=T())
+        ops.tied_attention(qkv[:, :, 0:H], qkv[:, :, H:2 * H], qkv[:, :, 2 * H:], out.view(B, N, Lr, H, dh).permute(0, 1, 3, 2, 4),
+                           att, w=w, qscale=self.scale, att_sym=att_sym)
+        xn_next = ops.linear_residual_ln(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln)
+        return att_sym, xn_next
+
     def forward(self, x):
         xn = ops.cast(x.contiguous(), T())
-        out = torch.zeros(x.shape, device=x.device, dtype=F32)
+        out = ops.zeros(*x.shape, device=x.device, dtype=F32)
         att, _ = self.attend(xn, out, self.return_att)
         return (out, att) if self.return_att else out
 
@@ -385,10 +550,10 @@ class PerformerSelfAttention(RFModule):
         self.heads, self.dim_head, self.inner = heads, dim_head, inner
         self.generalized = generalized_attention
         self.fast_attention = _FastAttention(dim_head, int(dim_head * math.log(dim_head)))
-        self.to_q = nn.Linear(dim, inner, bias=False)
-        self.to_k = nn.Linear(dim, inner, bias=False)
-        self.to_v = nn.Linear(dim, inner, bias=False)
-        self.to_out = nn.Linear(inner, dim)
+        self.to_q = Linear(dim, inner, bias=False)
+        self.to_k = Linear(dim, inner, bias=False)
+        self.to_v = Linear(dim, inner, bias=False)
+        self.to_out = Linear(inner, dim)
 
     def proj_scaled(self, log2e=False):
         def make():
@@ -471,8 +636,9 @@ class PerformerSelfAttention(RFModule):
             ops.favor_softmax_features(dq, qk, 0, xs, Lo, H, S, Ls, m, M_PAD, dh, 1, 0)
             ops.favor_softmax_features(kt, qk, inner, xs, Lo, H, S, Ls, m, M_PAD, dh, 0, 1)
         # v^T [B,Lo,H,80,Ls] with a ones row at index 64 (-> k' column sums ride along in the context GEMM)
-        vt = torch.zeros(B, Lo, H, VT_ROWS, Ls, device=dev, dtype=T())
-        vt[:, :, :, dh] = 1
+        vt = ops.zeros(B, Lo, H, VT_ROWS, Ls, device=dev, dtype=T())
+        ones_row = ops.fill(torch.empty(B * Lo * H, Ls, device=dev, dtype=T()), 1.0)
+        ops.copy4d(ones_row, (0, 0, Ls, 1), vt, (0, 0, VT_ROWS * Ls, 1), (1, 1, B * Lo * H, Ls), y_off=dh * Ls)
         ops.gemm(self.wt("v", self.to_v), xn, vt, inner, Ls, D, batch=(B, Lo, 1),
                  b_bs=(RB * D, so * D, 0), b_row=(0, 0, ss * D),
                  c_bs=(Lo * H * VT_ROWS * Ls, H * VT_ROWS * Ls, 0), c_row=(dh, VT_ROWS * Ls, Ls))
@@ -494,7 +660,7 @@ class PerformerSelfAttention(RFModule):
         """x [S, n, dim] -> [S, n, dim] (library call surface)."""
         S_, n, D = x.shape
         xn = ops.cast(x.contiguous(), T()).view(1, S_, n, D)
-        out = torch.zeros(1, S_, n, D, device=x.device, dtype=F32)
+        out = ops.zeros(1, S_, n, D, device=x.device, dtype=F32)
         self.attend(xn, out, axis=2)
         return out.view(S_, n, D)
 
@@ -518,8 +684,8 @@ class EncoderLayer(RFModule):
             self.attn = PerformerSelfAttention(dim=d_msa, heads=n_heads, dropout=p_dropout, **performer_kws)
         else:
             raise NotImplementedError
-        self.ln = nn.LayerNorm(d_msa)
-        self.ff = Residual(nn.Sequential(nn.LayerNorm(d_msa), FeedForward(d_msa, d_ff, p_dropout=p_dropout),
+        self.ln = LayerNorm(d_msa)
+        self.ff = Residual(nn.Sequential(LayerNorm(d_msa), FeedForward(d_msa, d_ff, p_dropout=p_dropout),
                                          nn.Dropout(p_dropout)))
 
     def run(self, x, seq_axis=2, want_att=False, xn=None, next_ln=None):
@@ -538,7 +704,7 @@ class EncoderLayer(RFModule):
         return att, self.ff.fn[1].apply_residual(xf, x, next_ln)
 
     def forward(self, x):
-        x = x.detach().float().clone().contiguous()
+        x = fresh_f32(x)
         if self.tied:
             att, _ = self.run(x, want_att=self.return_att)
             return (x, att) if self.return_att else x
@@ -575,7 +741,7 @@ class MsaUpdateUsingSelfAttention(RFModule):
         return att
 
     def forward(self, x):
-        x = x.detach().float().clone().contiguous()
+        x = fresh_f32(x)
         return x, self.run(x)
 
 
@@ -587,7 +753,7 @@ class OuterProductMean(RFModule):
 
     def __init__(self, in_features, out_features):
         super().__init__()
-        self.to_out = nn.Sequential(nn.LayerNorm(in_features ** 2), nn.Linear(in_features ** 2, out_features))
+        self.to_out = nn.Sequential(LayerNorm(in_features ** 2), Linear(in_features ** 2, out_features))
 
     def run(self, x_t, y_t, N):
         """x_t, y_t: T [B, L, P, N] (MSA depth contiguous).  -> fp32 [B,L,L,out]"""
@@ -612,8 +778,9 @@ class OuterProductMean(RFModule):
         y = x if y is None else y
         B, N, Lr, P = x.shape
         Np = pad8(N)
-        xt = torch.zeros(B, Lr, P, Np, device=x.device, dtype=T())
-        yt = torch.zeros(B, Lr, P, Np, device=x.device, dtype=T())
+        mk = ops.zeros if Np != N else torch.empty  # only the K padding needs zeros
+        xt = mk(B, Lr, P, Np, device=x.device, dtype=T())
+        yt = mk(B, Lr, P, Np, device=x.device, dtype=T())
         for src, dst in ((x, xt), (y, yt)):
             ops.copy4d(src.contiguous(), (N * Lr * P, P, 1, Lr * P), dst, (Lr * P * Np, P * Np, Np, 1), (B, Lr, P, N))
         return self.run(xt, yt, Np)
@@ -625,15 +792,15 @@ class PairUpdateWithMsa(RFModule):
     def __init__(self, d_msa, d_proj, d_pair, n_heads, p_dropout=0.1):
         super().__init__()
         self.d_proj, self.d_pair, self.n_heads = d_proj, d_pair, n_heads
-        self.proj_msa = nn.Sequential(nn.LayerNorm(d_msa), nn.Linear(d_msa, d_proj), nn.LayerNorm(d_proj))
+        self.proj_msa = nn.Sequential(LayerNorm(d_msa), Linear(d_msa, d_proj), LayerNorm(d_proj))
         self.poswise_weight = PositionWiseWeightFactor(d_proj, 1, p_dropout)
         self.outer_product_mean = OuterProductMean(d_proj, d_pair)
-        self.ln_coevol_feat = nn.LayerNorm(d_pair)
-        self.ln_pair = nn.LayerNorm(d_pair)
+        self.ln_coevol_feat = LayerNorm(d_pair)
+        self.ln_pair = LayerNorm(d_pair)
         d_feat_full = d_pair * 2 + d_proj * 4 + n_heads
         self.d_feat = d_feat_full
         self.resnet = nn.Sequential(
-            nn.Linear(d_feat_full, d_pair),
+            Linear(d_feat_full, d_pair),
             Residual(nn.Sequential(
                 nn.Identity(),
                 nn.Conv2d(d_pair, d_pair, kernel_size=3, padding="same", bias=False),
@@ -659,13 +826,14 @@ class PairUpdateWithMsa(RFModule):
         w = self.poswise_weight.weights(mp)  # fp32 [B,N,1,L]
         # 1-D features: sum over N and the query row
         msa1d = torch.empty(B, Lr, 2 * P, device=dev, dtype=F32)
-        ones = self.cached(("ones", B, N, Lr), lambda: torch.ones(B, N, 1, Lr, device=dev, dtype=F32))
+        ones = ops.fill(torch.empty(B, N, 1, Lr, device=dev, dtype=F32), 1.0)
         ops.weighted_msa_sum(mp, ones, msa1d, 2 * P)
         ops.copy4d(mp, (N * Lr * P, 0, P, 1), msa1d, (Lr * 2 * P, 0, 2 * P, 1), (B, 1, Lr, P), y_off=P)
         # transposed operands of the outer product: x_t[b,i,u,n] = mp ; y_t = mp * w   (rf.py:472-473)
-        mpw = ops.scale_rows(mp.clone(), w, B * N * Lr, P)
-        xt = torch.zeros(B, Lr, P, Np, device=dev, dtype=T())
-        yt = torch.zeros(B, Lr, P, Np, device=dev, dtype=T())
+        mpw = ops.scale_rows(mp, w, B * N * Lr, P)
+        mk = ops.zeros if Np != N else torch.empty  # only the K padding needs zeros
+        xt = mk(B, Lr, P, Np, device=dev, dtype=T())
+        yt = mk(B, Lr, P, Np, device=dev, dtype=T())
         for src, dst in ((mp, xt), (mpw, yt)):
             ops.copy4d(src, (N * Lr * P, P, 1, Lr * P), dst, (Lr * P * Np, P * Np, Np, 1), (B, Lr, P, N))
         coevol = self.outer_product_mean.run(xt, yt, Np)  # fp32 [B,L,L,Dp]
@@ -673,7 +841,9 @@ class PairUpdateWithMsa(RFModule):
         Kf = pad8(self.d_feat)
         feat = torch.empty(B, Lr, Lr, Kf, device=dev, dtype=T())  # every feature column is written below; only the K padding
         if Kf > self.d_feat:                                       # needs zeros (a full memset of this tensor is 0.38 GB)
-            feat[..., self.d_feat:].zero_()
+            zpad = ops.zeros(B * Lr * Lr, Kf - self.d_feat, device=dev, dtype=T())
+            ops.copy4d(zpad, (0, 0, Kf - self.d_feat, 1), feat, (0, 0, Kf, 1), (1, 1, B * Lr * Lr, Kf - self.d_feat),
+                       y_off=self.d_feat)
         ln(self.ln_coevol_feat, coevol, out=feat, out_ld=Kf, out_off=0)
         ops.tile_1d_feats(msa1d, feat, Kf, Dp, B, Lr, 2 * P)
         ln(self.ln_pair, pair, out=feat, out_ld=Kf, out_off=Dp + 4 * P)
@@ -718,9 +888,9 @@ class PairUpdateWithAxialAttentionLayer(RFModule):
         self.ff = FeedForward(d_pair, d_ff, p_dropout)
         # same aliasing as the reference: layer.k.fn.0 = LayerNorm, layer.0.fn.1.fn = row_attn, ...
         self.layer = nn.Sequential(
-            Residual(nn.Sequential(nn.LayerNorm(d_pair), Residual(self.row_attn))),
-            Residual(nn.Sequential(nn.LayerNorm(d_pair), Residual(self.col_attn))),
-            Residual(nn.Sequential(nn.LayerNorm(d_pair), self.ff)),
+            Residual(nn.Sequential(LayerNorm(d_pair), RowWise(self.row_attn))),
+            Residual(nn.Sequential(LayerNorm(d_pair), ColWise(self.col_attn))),
+            Residual(nn.Sequential(LayerNorm(d_pair), self.ff)),
         )
 
     def run(self, x, xn=None, next_ln=None):
@@ -737,7 +907,7 @@ class PairUpdateWithAxialAttentionLayer(RFModule):
         return self.ff.apply_residual(xn, x, next_ln)
 
     def forward(self, x):
-        x = x.detach().float().clone().contiguous()
+        x = fresh_f32(x)
         self.run(x)
         return x
 
@@ -757,7 +927,7 @@ class PairUpdateWithAxialAttention(RFModule):
             xn = layer.run(x, xn=xn, next_ln=nxt)
 
     def forward(self, x):
-        x = x.detach().float().clone().contiguous()
+        x = fresh_f32(x)
         self.run(x)
         return x
 
@@ -781,10 +951,10 @@ class MsaUpdateWithPairLayer(RFModule):
     def __init__(self, d_msa, d_pair, n_heads, p_dropout=0.1):
         super().__init__()
         self.n_heads = n_heads
-        self.pair2att = nn.Sequential(Symmetrization(), nn.LayerNorm(d_pair), nn.Linear(d_pair, n_heads),
+        self.pair2att = nn.Sequential(Symmetrization(), LayerNorm(d_pair), Linear(d_pair, n_heads),
                                       nn.Dropout(p_dropout), nn.Identity(), nn.Softmax(dim=-1))
-        self.msa2value = nn.Sequential(nn.LayerNorm(d_msa), nn.Linear(d_msa, d_msa), nn.Identity())
-        self.ff = Residual(nn.Sequential(nn.LayerNorm(d_msa), FeedForward(d_msa, d_msa, p_dropout)), p_dropout=p_dropout)
+        self.msa2value = nn.Sequential(LayerNorm(d_msa), Linear(d_msa, d_msa), nn.Identity())
+        self.ff = Residual(nn.Sequential(LayerNorm(d_msa), FeedForward(d_msa, d_msa, p_dropout)), p_dropout=p_dropout)
 
     def folded_att_proj(self):
         """LayerNorm affine folded into the 288->H projection: W' = W*gamma, b' = W beta + b (fp32)."""
@@ -853,13 +1023,13 @@ class MsaUpdateWithPair(RFModule):
             xn = layer.run(msa, att, xn=xn, next_ln=nxt)
 
     def forward(self, msa, pair):
-        msa = msa.detach().float().clone().contiguous()
+        msa = fresh_f32(msa)
         self.run(msa, pair.float().contiguous())
         return msa
 
 
 def _msa_update_with_pair_layer_forward(self, msa, pair):
-    msa = msa.detach().float().clone().contiguous()
+    msa = fresh_f32(msa)
     self.run(msa, pair_to_att([self], pair.float().contiguous())[0])
     return msa
 
@@ -876,11 +1046,11 @@ class GraphTransformer(RFModule):
     def __init__(self, d_node_in, d_node_out, d_edge, n_heads, p_dropout=0.15):
         super().__init__()
         self.scale = d_node_out ** (-0.5)
-        self.node_update = nn.Linear(d_node_in, d_node_out * n_heads, bias=True)
-        self.node_to_q = nn.Linear(d_node_in, d_node_out * n_heads, bias=True)
-        self.node_to_k = nn.Linear(d_node_in, d_node_out * n_heads, bias=True)
-        self.node_to_v = nn.Linear(d_node_in, d_node_out * n_heads, bias=True)
-        self.edge_emb = nn.Linear(d_edge, d_node_out * n_heads, bias=False)
+        self.node_update = Linear(d_node_in, d_node_out * n_heads, bias=True)
+        self.node_to_q = Linear(d_node_in, d_node_out * n_heads, bias=True)
+        self.node_to_k = Linear(d_node_in, d_node_out * n_heads, bias=True)
+        self.node_to_v = Linear(d_node_in, d_node_out * n_heads, bias=True)
+        self.edge_emb = Linear(d_edge, d_node_out * n_heads, bias=False)
         self.n_heads, self.d_out = n_heads, d_node_out
 
     def run(self, node, edge_t):
@@ -908,8 +1078,8 @@ class GraphTransformerBlock(RFModule):
     def __init__(self, d_node_in, d_node_out, d_edge, n_heads, p_dropout=0.15):
         super().__init__()
         self.attn = GraphTransformer(d_node_in, d_node_out, d_edge, n_heads, p_dropout)
-        self.ln = nn.LayerNorm(d_node_out * n_heads)
-        self.to_out = nn.Sequential(nn.Linear(d_node_out * n_heads, d_node_in), nn.ELU())
+        self.ln = LayerNorm(d_node_out * n_heads)
+        self.to_out = nn.Sequential(Linear(d_node_out * n_heads, d_node_in), nn.ELU())
 
     def run(self, node, edge_t):
         h = ln(self.ln, self.attn.run(node, edge_t))
@@ -926,9 +1096,9 @@ def _node_input(mod, msa, seq_onehot, out_dtype=None):
     m = ln(mod.ln_msa, msa)
     w = mod.poswise_weight.weights_collapsed(msa, mod.ln_msa, m)
     Kp = pad8(D + 21)
-    tmp = torch.zeros(B, Lr, Kp, device=msa.device, dtype=F32)
+    tmp = ops.zeros(B, Lr, Kp, device=msa.device, dtype=F32)
     ops.weighted_msa_sum(m, w, tmp, Kp)
-    tmp[:, :, D:D + 21] = seq_onehot
+    ops.copy4d(seq_onehot.contiguous(), (0, 0, 21, 1), tmp, (0, 0, Kp, 1), (1, 1, B * Lr, 21), y_off=D)
     return ops.cast(tmp, out_dtype or T()), Kp
 
 
@@ -937,14 +1107,14 @@ class InitialCoordGenerationWithMsaAndPair(RFModule):
 
     def __init__(self, d_msa, d_pair, d_node=64, d_edge=64, n_heads=4, n_layers=4, p_dropout=0.1):
         super().__init__()
-        self.ln_msa = nn.LayerNorm(d_msa)
-        self.ln_pair = nn.LayerNorm(d_pair)
+        self.ln_msa = LayerNorm(d_msa)
+        self.ln_pair = LayerNorm(d_pair)
         self.poswise_weight = PositionWiseWeightFactor(d_msa, 1, p_dropout)
-        self.node_embed = nn.Sequential(nn.Linear(d_msa + 21, d_node), nn.ELU())
-        self.edge_embed = nn.Sequential(nn.Linear(d_pair + 1, d_edge), nn.ELU())
+        self.node_embed = nn.Sequential(Linear(d_msa + 21, d_node), nn.ELU())
+        self.edge_embed = nn.Sequential(Linear(d_pair + 1, d_edge), nn.ELU())
         self.blocks = nn.ModuleList([GraphTransformerBlock(d_node, d_node, d_edge, n_heads, p_dropout)
                                      for _ in range(n_layers)])
-        self.to_out = nn.Linear(d_node, 9)
+        self.to_out = Linear(d_node, 9)
 
     def run(self, msa, pair, seq_onehot, aa_idx):
         B, Lr, _, Dp = pair.shape
@@ -952,10 +1122,9 @@ class InitialCoordGenerationWithMsaAndPair(RFModule):
         node = ops.linear(nin, self.wt("n", self.node_embed[0], kpad=Kp), _f(self.node_embed[0].bias), out_dtype=F32,
                           act=L.ACT_ELU)
         Ke = pad8(Dp + 1)
-        ein = torch.zeros(B, Lr, Lr, Ke, device=pair.device, dtype=T())
+        ein = ops.zeros(B, Lr, Lr, Ke, device=pair.device, dtype=T())
         ln(self.ln_pair, pair, out=ein, out_ld=Ke)
-        dist = aa_idx.unsqueeze(-1) - aa_idx.unsqueeze(-2)
-        ein[..., Dp] = (torch.sign(dist) * torch.log(torch.abs(dist) + 1)).clamp(0.0, 5.5).to(T())  # rf.py:746-749
+        ops.seqsep_feature(aa_idx.contiguous(), ein, Ke, Dp)  # clamp(sign(d) log(|d|+1), 0, 5.5), rf.py:746-749
         edge = ops.linear(ein, self.wt("e", self.edge_embed[0], kpad=Ke), _f(self.edge_embed[0].bias), act=L.ACT_ELU)
         for blk in self.blocks:
             node = blk.run(node, edge)
@@ -1032,14 +1201,16 @@ class PredictionHead(RFModule):
     def __init__(self, in_channels, n_res_blocks, p_dropout):
         super().__init__()
         c = in_channels
-        self.proj = nn.Sequential(nn.LayerNorm(c), nn.Linear(c, c), nn.Dropout(p_dropout), nn.Identity())
+        self.proj = nn.Sequential(LayerNorm(c), Linear(c, c), nn.Dropout(p_dropout), nn.Identity())
         self.dist_head = nn.Sequential(ResNet(n_res_blocks, c, c, 37, p_dropout=p_dropout), nn.Identity())
         self.omega_head = nn.Sequential(ResNet(n_res_blocks, c, c, 37, p_dropout=p_dropout), nn.Identity())
         self.theta_head = nn.Sequential(ResNet(n_res_blocks, c, c, 37, p_dropout=p_dropout), nn.Identity())
         self.phi_head = nn.Sequential(ResNet(n_res_blocks, c, c, 19, p_dropout=p_dropout), nn.Identity())
 
     def forward(self, pair):
-        pair = pair.float().contiguous()
+        return self.run(pair.float().contiguous())
+
+    def run(self, pair):
         B, Lr, _, Cc = pair.shape
         x = ops.linear(ln(self.proj[0], pair), self.wt("p", self.proj[1]), _f(self.proj[1].bias), out_dtype=F32)
         xt = torch.empty_like(x)

@@ -2,13 +2,17 @@
 
 PyTorch is used here for device memory (tensors), the current HIP stream and dtype tags only;
 every arithmetic step is a kernel of librfmi.so reached through ctypes with raw device pointers.
+
+Device rule: every operand of a call lives on ONE device and that device is the calling thread's current device
+(kernels are enqueued on its current stream); anything else raises RfmiError instead of launching on the wrong GPU.
+`RoseTTAFold.forward` enters `torch.cuda.device(input.device)` itself, so the model can live on any GPU.
 """
 import ctypes as C
 
 import torch
 
 from . import _lib as L
-from ._lib import lib, check, GemmDesc, I64x4
+from ._lib import lib, check, GemmDesc, I64x4, I64x3
 
 F32, BF16 = torch.float32, torch.bfloat16
 
@@ -36,9 +40,19 @@ def _i4(v):
 
 
 def _need_cuda(*ts):
+    dev = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise L.RfmiError("librfmi ops need device tensors (there is no CPU fallback)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise L.RfmiError(f"operands on different devices: {dev} and {t.device}")
+    if dev is not None and dev.index != torch.cuda.current_device():
+        raise L.RfmiError(f"operands live on {dev} but the current device is cuda:{torch.cuda.current_device()} "
+                          "(wrap the call in torch.cuda.device(...))")
 
 
 # --------------------------------------------------------------------------------------------- GEMM
@@ -149,6 +163,51 @@ def tied_logits_softmax(q, k, b_stride, n_stride, l_stride, att, att_sym, B, H, 
                                      att_sym.shape[-1] if att_sym is not None else 0, B, H, N, L_, d_head, stream()),
           "rf_tied_logits_softmax")
     return att
+
+
+def _hstrides(t):
+    """(b, n, h, l) element strides of a [B, N, H, L, 32]-indexed view (head slice contiguous)."""
+    if t.dim() != 5 or t.stride(4) != 1 or t.shape[4] != 32:
+        raise ValueError("expected a [B, N, H, L, 32] view with a contiguous head dimension")
+    return I64x4(t.stride(0), t.stride(1), t.stride(2), t.stride(3))
+
+
+def tied_attention(q, k, v, out, att, w=None, qscale=1.0, att_sym=None):
+    """Tied MSA-row attention core (csrc/tied.hip).  q, k, v, out: bf16 views indexed [B, N, H, L, 32] (any strides with
+    a contiguous head slice); att: bf16 [B, H, L, L] (workspace + result); w: fp32 [B, H, N, L] position weights folded
+    into the logits kernel (None: q already carries them); att_sym: fp32 [B, L, L, H] or None."""
+    B, N, H, L_, dh = q.shape
+    _need_cuda(q, k, v, out, att, w, att_sym)
+    if q.stride() != k.stride():
+        raise ValueError("q and k must share their strides")
+    ws = I64x3(w.stride(0), w.stride(1), w.stride(2)) if w is not None else I64x3(0, 0, 0)
+    if w is not None and (w.stride(3) != 1 or tuple(w.shape) != (B, H, N, L_)):
+        raise ValueError("w must be [B, H, N, L] with contiguous L")
+    check(lib.rf_tied_attention(ptr(q), ptr(k), ptr(v), C.byref(_hstrides(q)), C.byref(_hstrides(v)), ptr(w), C.byref(ws),
+                                float(qscale), ptr(att), ptr(att_sym), att_sym.shape[-1] if att_sym is not None else 0,
+                                ptr(out), C.byref(_hstrides(out)), B, H, N, L_, dh, stream()), "rf_tied_attention")
+    return out
+
+
+def tied_row_attention(q, k, v):
+    """Functional form for the dispatcher op: q, k, v bf16 [B, N, L, H, 32] -> (out [B, N, L, H*32], att_sym [B, L, L, H])."""
+    B, N, L_, H, dh = q.shape
+    out = torch.empty(B, N, L_, H * dh, device=q.device, dtype=BF16)
+    att = torch.empty(B, H, L_, L_, device=q.device, dtype=BF16)
+    sym = torch.empty(B, L_, L_, H, device=q.device, dtype=F32)
+    hm = lambda t: t.permute(0, 1, 3, 2, 4)  # noqa: E731  [B, N, H, L, 32] view
+    tied_attention(hm(q.contiguous()), hm(k.contiguous()), hm(v.contiguous()), hm(out.view(B, N, L_, H, dh)), att, att_sym=sym)
+    return out, sym
+
+
+def poswise_collapsed(xn, u, scale):
+    """w[b,h,n,l] = softmax_n(scale * xn[b,n,l,:] . u[b,l,h,:]); xn bf16 [B,N,L,D], u bf16 [B,L,H,D] -> fp32 [B,H,N,L]."""
+    B, N, L_, D = xn.shape
+    H = u.shape[2]
+    _need_cuda(xn, u)
+    w = torch.empty(B, H, N, L_, device=xn.device, dtype=F32)
+    check(lib.rf_poswise_collapsed(ptr(xn), ptr(u), ptr(w), B, N, L_, D, H, float(scale), stream()), "rf_poswise_collapsed")
+    return w
 
 
 def tied_softmax(logits, att, att_sym=None, sym_ld=0):
@@ -273,14 +332,16 @@ def knn_mask(xyz, aa_idx, k, kmin=9):
 
 
 def edges_from_mask(mask, capacity):
+    """count = [min(edges, capacity), edges]; src/dst beyond count[0] are never read by the consumers."""
     B, L_, _ = mask.shape
     dev = mask.device
-    src = torch.zeros(capacity, device=dev, dtype=torch.int32)
-    dst = torch.zeros(capacity, device=dev, dtype=torch.int32)
+    _need_cuda(mask)
+    src = torch.empty(capacity, device=dev, dtype=torch.int32)
+    dst = torch.empty(capacity, device=dev, dtype=torch.int32)
     eid = torch.empty(B, L_, L_, device=dev, dtype=torch.int32)
-    count = torch.zeros(1, device=dev, dtype=torch.int32)
+    count = torch.empty(2, device=dev, dtype=torch.int32)
     ws = torch.empty(2 * B * L_, device=dev, dtype=torch.int32)
-    check(lib.rf_edges_from_mask(ptr(mask), ptr(src), ptr(dst), ptr(eid), ptr(count), ptr(ws), B, L_, stream()),
+    check(lib.rf_edges_from_mask(ptr(mask), ptr(src), ptr(dst), ptr(eid), ptr(count), ptr(ws), B, L_, capacity, stream()),
           "rf_edges_from_mask")
     return src, dst, eid, count
 
@@ -297,18 +358,29 @@ def se3_edge_geometry(xyz, edge_emb, src, dst, count, capacity):
 
 
 def se3_message(R0, R1, basis, h0, h1, src, count, mo, dout, mi0, mi1, capacity):
-    msg = torch.zeros(capacity, mo, 2 * dout + 1, device=basis.device, dtype=F32)
+    msg = torch.empty(capacity, mo, 2 * dout + 1, device=basis.device, dtype=F32)  # rows >= count are never read
     check(lib.rf_se3_message(ptr(R0), ptr(R1), ptr(basis), ptr(h0), ptr(h1), ptr(src), ptr(count), ptr(msg), mo, dout,
                              mi0, mi1, capacity, stream()), "rf_se3_message")
     return msg
 
 
-def se3_attention(k0, k1, q0, q1, v0, v1, eid, heads, mk0, mk1, mv0, mv1, V, L_):
+def se3_attention(k0, k1, q0, q1, v0, v1, eid, heads, mk0, mk1, mv0, mv1, V, L_, skip0=None, skip1=None):
+    """out_d [V, mv_d (+ skip channels), 2d+1]: the attention result in the leading channels; with skip_d the node's
+    input features are appended behind it (GCat, ea/modules.py:903-928) -- one buffer, no concatenation pass."""
     dev = k0.device
-    out0 = torch.empty(V, mv0, 1, device=dev, dtype=F32)
-    out1 = torch.empty(V, mv1, 3, device=dev, dtype=F32)
+    c0 = mv0 + (skip0.shape[1] if skip0 is not None else 0)
+    c1 = mv1 + (skip1.shape[1] if skip1 is not None else 0)
+    out0 = torch.empty(V, c0, 1, device=dev, dtype=F32)
+    out1 = torch.empty(V, c1, 3, device=dev, dtype=F32)
+    _need_cuda(k0, q0, v0, eid)
     check(lib.rf_se3_attention(ptr(k0), ptr(k1), ptr(q0), ptr(q1), ptr(v0), ptr(v1), ptr(eid), ptr(out0), ptr(out1),
-                               heads, mk0, mk1, mv0, mv1, V, L_, stream()), "rf_se3_attention")
+                               heads, mk0, mk1, mv0, mv1, V, L_, c0, 3 * c1, stream()), "rf_se3_attention")
+    if skip0 is not None:
+        m = skip0.shape[1]
+        copy4d(skip0, (0, 0, m, 1), out0, (0, 0, c0, 1), (1, 1, V, m), y_off=mv0)
+    if skip1 is not None:
+        m = skip1.shape[1] * 3
+        copy4d(skip1, (0, 0, m, 1), out1, (0, 0, 3 * c1, 1), (1, 1, V, m), y_off=3 * mv1)
     return out0, out1
 
 
@@ -345,10 +417,70 @@ def center_ca(xyz):
     return y
 
 
-def scale_rows(x, w, rows, D):
-    _need_cuda(x, w)
-    check(lib.rf_scale_rows(ptr(x), dcode(x.dtype), ptr(w), rows, D, stream()), "rf_scale_rows")
-    return x
+def scale_rows(x, w, rows, D, out=None):
+    """out[r, :] = x[r, :] * w[r]  (out defaults to a fresh tensor; pass out=x for in place)."""
+    if out is None:
+        out = torch.empty_like(x)
+    _need_cuda(x, w, out)
+    check(lib.rf_scale_rows(ptr(x), ptr(out), dcode(x.dtype), ptr(w), rows, D, stream()), "rf_scale_rows")
+    return out
+
+
+def fill(y, value=0.0):
+    """y[...] = value through rf_fill (fp32 / bf16 contiguous tensors; int32 tensors are zero-filled as fp32 words)."""
+    _need_cuda(y)
+    if not y.is_contiguous():
+        raise ValueError("fill: contiguous tensors only")
+    if y.dtype == torch.int32:
+        if value != 0:
+            raise ValueError("fill: int32 tensors can only be zeroed")
+        code = L.RF_F32
+    else:
+        code = dcode(y.dtype)
+    check(lib.rf_fill(ptr(y), code, float(value), y.numel(), stream()), "rf_fill")
+    return y
+
+
+def zeros(*shape, device, dtype):
+    return fill(torch.empty(*shape, device=device, dtype=dtype), 0.0)
+
+
+def check_inputs(msa, seq, aa_idx, d_input, max_len):
+    """One launch + one 12-byte read-back: (token out of range, aa_idx out of range, aa_idx not strictly increasing)."""
+    ref = aa_idx if aa_idx is not None else (msa if msa is not None else seq)
+    _need_cuda(msa, seq, aa_idx)
+    flags = zeros(4, device=ref.device, dtype=torch.int32)
+    L_ = aa_idx.shape[-1] if aa_idx is not None else 1
+    check(lib.rf_check_inputs(ptr(msa), msa.numel() if msa is not None else 0, ptr(seq), seq.numel() if seq is not None else 0,
+                              ptr(aa_idx), aa_idx.numel() if aa_idx is not None else 0, L_, d_input, max_len, ptr(flags),
+                              stream()), "rf_check_inputs")
+    f = flags.tolist()
+    return bool(f[0]), bool(f[1]), bool(f[2])
+
+
+def onehot(idx, n_classes, out=None, out_ld=None, col0=0, dtype=F32):
+    rows = idx.numel()
+    if out is None:
+        out = torch.empty(*idx.shape, n_classes, device=idx.device, dtype=dtype)
+        out_ld = n_classes
+    _need_cuda(idx, out)
+    check(lib.rf_onehot(ptr(idx), ptr(out), dcode(out.dtype), out_ld, col0, n_classes, rows, stream()), "rf_onehot")
+    return out
+
+
+def seqsep_feature(aa_idx, out, out_ld, col):
+    B, L_ = aa_idx.shape
+    _need_cuda(aa_idx, out)
+    check(lib.rf_seqsep_feature(ptr(aa_idx), ptr(out), dcode(out.dtype), out_ld, col, B, L_, stream()), "rf_seqsep_feature")
+    return out
+
+
+def add_pos_enc(x, aa_idx, pe, two_d):
+    B, N, L_, D = x.shape
+    y = torch.empty_like(x)
+    _need_cuda(x, aa_idx, pe)
+    check(lib.rf_add_pos_enc(ptr(x), ptr(aa_idx), ptr(pe), ptr(y), B, N, L_, D, 1 if two_d else 0, stream()), "rf_add_pos_enc")
+    return y
 
 
 def favor_attention(qkv, pc, out, x_strides, o_strides, q_off, k_off, v_off, n_b, n_o, n_h, seq_len, dim_head,

@@ -34,18 +34,55 @@ def unpack_results(flat, B, L):
     return out, xyz, flat[o:o + B * L].view(B, L)
 
 
-def gather_results(logits, xyz, plddt, dst=0):
+def result_numel(B, L):
+    return B * L * L * sum(LOGIT_BINS.values()) + B * L * 9 + B * L
+
+
+def gather_results(logits, xyz, plddt, dst=0, batch_sizes=None):
     """Gather every rank's results on `dst`; returns a list of (logits, xyz, plddt) on dst, None elsewhere.
-    All ranks must hold the same per-rank batch size (weak scaling)."""
+    batch_sizes: per-rank batch sizes when they differ (uneven shards: every rank pads its flat buffer to the largest
+    shard, `torch.distributed.gather` needs equal sizes); None = all ranks hold the same batch size (weak scaling)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [(logits, xyz, plddt)]
     B, L = plddt.shape
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if batch_sizes is None:
+        batch_sizes = [B] * world
+    if len(batch_sizes) != world or batch_sizes[rank] != B:
+        raise ValueError(f"batch_sizes {batch_sizes} does not describe this rank (rank {rank} holds {B})")
     flat = pack_results(logits, xyz, plddt)
+    nmax = result_numel(max(batch_sizes), L)
+    if flat.numel() < nmax:
+        flat = torch.cat([flat, flat.new_zeros(nmax - flat.numel())])
     if dist.get_backend() == "gloo" and flat.is_cuda:
         flat = flat.cpu()  # gloo has no device gather; RCCL ("nccl") gathers in HBM
-    world, rank = dist.get_world_size(), dist.get_rank()
     bufs = [torch.empty_like(flat) for _ in range(world)] if rank == dst else None
     dist.gather(flat, bufs, dst=dst)
     if rank != dst:
         return None
-    return [unpack_results(b, B, L) for b in bufs]
+    return [unpack_results(b[:result_numel(n, L)], n, L) for b, n in zip(bufs, batch_sizes) if n > 0]
+
+
+def forward_sharded(model, msa, seq, aa_idx, dst=0):
+    """Data-parallel forward of a GLOBAL batch (BASELINE.json configs[2]: bsz=32 over 8 GPUs): every rank receives the
+    same global (msa [B,N,L], seq [B,L], aa_idx [B,L]) tensors (host or device), runs the forward on its contiguous
+    slice `shard_range(B, world, rank)` on its own GPU and the results meet on `dst` in one gather.  Returns
+    (logits, xyz, plddt) of the whole batch on dst (concatenated in batch order), None on the other ranks.  Samples are
+    independent, so the result equals the single-process forward of the same batch sample by sample."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    B = msa.shape[0]
+    sizes = [shard_range(B, world, r)[1] - shard_range(B, world, r)[0] for r in range(world)]
+    lo, hi = shard_range(B, world, rank)
+    dev = next(model.parameters()).device
+    L = msa.shape[-1]
+    if hi > lo:
+        logits, xyz, plddt = model(msa[lo:hi].to(dev), seq[lo:hi].to(dev), aa_idx[lo:hi].to(dev))
+    else:  # more ranks than samples: this rank contributes nothing
+        logits = {k: torch.zeros(0, L, L, n, device=dev) for k, n in LOGIT_BINS.items()}
+        xyz, plddt = torch.zeros(0, L, 3, 3, device=dev), torch.zeros(0, L, device=dev)
+    parts = gather_results(logits, xyz, plddt, dst=dst, batch_sizes=sizes)
+    if parts is None:
+        return None
+    out = {k: torch.cat([p[0][k] for p in parts]) for k in LOGIT_KEYS}
+    return out, torch.cat([p[1] for p in parts]), torch.cat([p[2] for p in parts])

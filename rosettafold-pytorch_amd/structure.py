@@ -12,7 +12,8 @@ from . import ops
 from .ops import F32
 from .model import (RFModule, Residual, FeedForward, PositionWiseWeightFactor, MsaEmbedding, PairEmbedding,
                     MsaUpdateUsingSelfAttention, PairUpdateWithMsa, PairUpdateWithAxialAttention, MsaUpdateWithPair,
-                    InitialCoordGenerationWithMsaAndPair, PredictionHead, _node_input, _f, ln, T, pad8, CA_IDX)
+                    InitialCoordGenerationWithMsaAndPair, PredictionHead, LayerNorm, Linear, _node_input, _f, ln, T, pad8,
+                    CA_IDX, fresh_f32, check_index_range)
 
 
 # ================================================================================================
@@ -23,7 +24,7 @@ class BN(nn.Module):
 
     def __init__(self, m):
         super().__init__()
-        self.bn = nn.LayerNorm(m)
+        self.bn = LayerNorm(m)
 
 
 class RadialFunc(nn.Module):
@@ -32,8 +33,8 @@ class RadialFunc(nn.Module):
     def __init__(self, num_freq, in_dim, out_dim, edge_dim=0):
         super().__init__()
         self.num_freq, self.in_dim, self.out_dim, self.edge_dim, self.mid_dim = num_freq, in_dim, out_dim, edge_dim, 32
-        self.net = nn.Sequential(nn.Linear(edge_dim + 1, 32), BN(32), nn.ReLU(), nn.Linear(32, 32), BN(32), nn.ReLU(),
-                                 nn.Linear(32, num_freq * in_dim * out_dim))
+        self.net = nn.Sequential(Linear(edge_dim + 1, 32), BN(32), nn.ReLU(), Linear(32, 32), BN(32), nn.ReLU(),
+                                 Linear(32, num_freq * in_dim * out_dim))
         nn.init.kaiming_uniform_(self.net[0].weight)
         nn.init.kaiming_uniform_(self.net[3].weight)
         nn.init.kaiming_uniform_(self.net[6].weight)
@@ -106,9 +107,9 @@ class GAttentiveSelfInt(nn.Module):
         self.transform = nn.ModuleDict()
         for d, mi in f_in.items():
             mo = f_out[d]
-            lin = nn.Linear(mi * mi, mi * mo, bias=True)
+            lin = Linear(mi * mi, mi * mo, bias=True)
             nn.init.kaiming_uniform_(lin.weight)
-            self.transform[str(d)] = nn.Sequential(nn.LayerNorm(mi * mi), nn.LeakyReLU(), lin)
+            self.transform[str(d)] = nn.Sequential(LayerNorm(mi * mi), nn.LeakyReLU(), lin)
 
     def run(self, h):
         out = {}
@@ -177,6 +178,10 @@ class GSE3Res(nn.Module):
         object.__setattr__(self, "_rfc", None)
         return super()._apply(fn, *a, **k)
 
+    def _load_from_state_dict(self, *a, **k):
+        object.__setattr__(self, "_rfc", None)  # packed radial weights are rebuilt from the loaded parameters
+        return super()._load_from_state_dict(*a, **k)
+
     def run(self, h, g):
         """h: {0: [V,m0,1], 1: [V,m1,3]} fp32;  g: graph dict (src, dst, eid, count, basis, feat, cap, V, L)."""
         nets = self._nets()
@@ -211,11 +216,11 @@ class GSE3Res(nn.Module):
                                                    g["src"], g["count"], mo, do, mi0, mi1, cap)
         q = self.GMAB["q"].run(h)
         fk, fv = self.f_mid_in, self.f_mid_out
+        # skip connection 'cat' (GCat, ea/modules.py:903-928): the attention writes the leading channels of the
+        # concatenated buffers, the node's input features are copied in behind them
         z0, z1 = ops.se3_attention(msg[("k", 0)], msg[("k", 1)], q[0], q[1], msg[("v", 0)], msg[("v", 1)], g["eid"],
-                                   self.n_heads, fk[0], fk[1], fv[0], fv[1], g["V"], g["L"])
-        z = {0: z0, 1: z1}
-        zc = {d: (torch.cat([z[d], h[d]], 1) if d in h else z[d]) for d in z}
-        return self.project.run(zc)
+                                   self.n_heads, fk[0], fk[1], fv[0], fv[1], g["V"], g["L"], skip0=h.get(0), skip1=h.get(1))
+        return self.project.run({0: z0, 1: z1})
 
 
 class SE3Transformer(nn.Module):
@@ -246,12 +251,14 @@ class SE3Transformer(nn.Module):
         return h
 
 
-def build_graph(xyz, edge_emb, aa_idx, n_neighbors, kmin=9):
+def build_graph(xyz, edge_emb, aa_idx, n_neighbors, kmin=9, monotonic=True):
     """rf.py:823-862 on the device: dense mask -> compacted edge list (+ dense edge-id map) -> per-edge geometry.
-    The edge count stays on the device; every per-edge buffer has the static capacity B*L*min(L, k+2*(kmin-1))."""
+    The edge count stays on the device; every per-edge buffer has a static capacity: B*L*min(L, k+2*(kmin-1)) when
+    aa_idx is strictly increasing inside each sample (at most 2*(kmin-1) sequence neighbours besides the k nearest),
+    B*L*L otherwise.  The compaction kernel never writes past the capacity (rf_edges_from_mask)."""
     B, Lr = xyz.shape[:2]
     k = min(n_neighbors, Lr)
-    per_row = min(Lr, k + 2 * (kmin - 1))
+    per_row = min(Lr, k + 2 * (kmin - 1)) if monotonic else Lr
     cap = (B * Lr * per_row + 63) // 64 * 64
     mask = ops.knn_mask(xyz, aa_idx, k, kmin)
     src, dst, eid, count = ops.edges_from_mask(mask, cap)
@@ -266,16 +273,16 @@ class CoordUpdateWithMsaAndPair(RFModule):
     def __init__(self, d_msa, d_pair, d_node, d_edge, d_state, n_neighbors, p_dropout=0.1):
         super().__init__()
         self.n_neighbors = n_neighbors
-        self.ln_msa = nn.LayerNorm(d_msa)
-        self.ln_pair = nn.LayerNorm(d_pair)
+        self.ln_msa = LayerNorm(d_msa)
+        self.ln_pair = LayerNorm(d_pair)
         self.poswise_weight = PositionWiseWeightFactor(d_msa, 1, p_dropout)
-        self.node_embed = nn.Sequential(nn.Linear(d_msa + 21, d_node), nn.ELU(), nn.LayerNorm(d_node))
-        self.edge_embed = nn.Sequential(nn.Linear(d_pair, d_edge), nn.ELU(), nn.LayerNorm(d_edge))
+        self.node_embed = nn.Sequential(Linear(d_msa + 21, d_node), nn.ELU(), LayerNorm(d_node))
+        self.edge_embed = nn.Sequential(Linear(d_pair, d_edge), nn.ELU(), LayerNorm(d_edge))
         self.se3_transformer = SE3Transformer(num_layers=2, num_channels=16, n_heads=4, num_degrees=2,
                                               l0_in_features=d_node, l1_in_features=3, l0_out_features=d_state,
                                               l1_out_features=3, num_edge_features=d_edge)
 
-    def run(self, xyz, msa, pair, aa_idx, seq_onehot):
+    def run(self, xyz, msa, pair, aa_idx, seq_onehot, monotonic=True):
         B, Lr = xyz.shape[:2]
         # the structure track is fp32 end to end (se3_modules.py:164): its input projections use the exact fp32 GEMM
         nin, Kp = _node_input(self, msa, seq_onehot, out_dtype=F32)
@@ -289,7 +296,7 @@ class CoordUpdateWithMsaAndPair(RFModule):
                        _f(self.edge_embed[0].bias), out_dtype=F32, act=L.ACT_ELU)
         edge = ln(self.edge_embed[2], e, out_dtype=F32)  # [B,L,L,d_edge] fp32
         xyz = xyz.contiguous()
-        g = build_graph(xyz, edge, aa_idx.contiguous(), self.n_neighbors)
+        g = build_graph(xyz, edge, aa_idx.contiguous(), self.n_neighbors, monotonic=monotonic)
         type0 = node.view(B * Lr, -1, 1)
         type1 = ops.center_ca(xyz).view(B * Lr, 3, 3)
         out = self.se3_transformer.run(g, type0, type1)
@@ -297,7 +304,9 @@ class CoordUpdateWithMsaAndPair(RFModule):
         return state, ops.coord_apply(xyz, out[1].contiguous())
 
     def forward(self, xyz, msa, pair, aa_idx, seq_onehot):
-        return self.run(xyz.float(), msa.float().contiguous(), pair.float().contiguous(), aa_idx, seq_onehot.float())
+        mono = check_index_range(None, None, aa_idx.contiguous(), 1, 1 << 62)
+        return self.run(xyz.float(), msa.float().contiguous(), pair.float().contiguous(), aa_idx, seq_onehot.float(),
+                        monotonic=mono)
 
 
 # ================================================================================================
@@ -312,13 +321,13 @@ class MsaUpdateWithPairAndCoord(RFModule):
         self.n_heads = len(distance_bins)
         self.d_inner = d_trfm_inner
         self.scale = (d_state // self.n_heads) ** -0.5  # rf.py:874
-        self.ln_msa = nn.LayerNorm(d_msa)
-        self.ln_state = nn.LayerNorm(d_state)
-        self.to_q = nn.Linear(d_state, d_trfm_inner * self.n_heads)
-        self.to_k = nn.Linear(d_state, d_trfm_inner * self.n_heads)
-        self.to_v = nn.Linear(d_msa, d_msa)
-        self.ln_out = nn.LayerNorm(d_msa)
-        self.to_out = Residual(nn.Sequential(nn.LayerNorm(d_msa), FeedForward(d_msa, d_ff, p_dropout)))
+        self.ln_msa = LayerNorm(d_msa)
+        self.ln_state = LayerNorm(d_state)
+        self.to_q = Linear(d_state, d_trfm_inner * self.n_heads)
+        self.to_k = Linear(d_state, d_trfm_inner * self.n_heads)
+        self.to_v = Linear(d_msa, d_msa)
+        self.ln_out = LayerNorm(d_msa)
+        self.to_out = Residual(nn.Sequential(LayerNorm(d_msa), FeedForward(d_msa, d_ff, p_dropout)))
 
     def run(self, xyz, state, msa):
         """returns the new fp32 msa [B,N,L,D] (the residual base is LayerNorm(msa), rf.py:893,918)."""
@@ -380,7 +389,7 @@ class TwoTrackBlock(RFModule):
         return pair
 
     def forward(self, msa, pair):
-        msa = msa.detach().float().clone().contiguous()
+        msa = fresh_f32(msa)
         pair = self.run(msa, pair.float().contiguous())
         return msa, pair
 
@@ -397,15 +406,16 @@ class ThreeTrackBlock(TwoTrackBlock):
                                                                         d_ff=d_msa * 4, distance_bins=[8, 12, 16, 20],
                                                                         p_dropout=p_dropout)
 
-    def run3(self, msa, pair, xyz, seq_onehot, aa_idx):
+    def run3(self, msa, pair, xyz, seq_onehot, aa_idx, monotonic=True):
         pair = self.run(msa, pair)
-        state, xyz = self.coord_update_with_msa_and_pair.run(xyz, msa, pair, aa_idx, seq_onehot)
+        state, xyz = self.coord_update_with_msa_and_pair.run(xyz, msa, pair, aa_idx, seq_onehot, monotonic)
         msa = self.msa_update_with_pair_and_coord.run(xyz, state, msa)
         return msa, pair, xyz
 
     def forward(self, msa, pair, xyz, seq_onehot, aa_idx):
-        msa = msa.detach().float().clone().contiguous()
-        return self.run3(msa, pair.float().contiguous(), xyz.float(), seq_onehot.float(), aa_idx)
+        msa = fresh_f32(msa)
+        mono = check_index_range(None, None, aa_idx.contiguous(), 1, 1 << 62)
+        return self.run3(msa, pair.float().contiguous(), xyz.float(), seq_onehot.float(), aa_idx, mono)
 
 
 class FinalBlock(TwoTrackBlock):
@@ -416,17 +426,18 @@ class FinalBlock(TwoTrackBlock):
         self.coord_update_with_msa_and_pair = CoordUpdateWithMsaAndPair(d_msa=d_msa, d_pair=d_pair, d_node=d_node,
                                                                         d_edge=d_edge, d_state=d_state,
                                                                         n_neighbors=n_neighbors, p_dropout=p_dropout)
-        self.plddt_head = nn.Linear(d_state, 1)
+        self.plddt_head = Linear(d_state, 1)
 
-    def run3(self, msa, pair, xyz, seq_onehot, aa_idx):
+    def run3(self, msa, pair, xyz, seq_onehot, aa_idx, monotonic=True):
         pair = self.run(msa, pair)
-        state, xyz = self.coord_update_with_msa_and_pair.run(xyz, msa, pair, aa_idx, seq_onehot)
+        state, xyz = self.coord_update_with_msa_and_pair.run(xyz, msa, pair, aa_idx, seq_onehot, monotonic)
         plddt = ops.linear(state.contiguous(), self.plddt_head.weight.detach(), _f(self.plddt_head.bias), out_dtype=F32)
         return msa, pair, xyz, plddt[..., 0]
 
     def forward(self, msa, pair, xyz, seq_onehot, aa_idx):
-        msa = msa.detach().float().clone().contiguous()
-        return self.run3(msa, pair.float().contiguous(), xyz.float(), seq_onehot.float(), aa_idx)
+        msa = fresh_f32(msa)
+        mono = check_index_range(None, None, aa_idx.contiguous(), 1, 1 << 62)
+        return self.run3(msa, pair.float().contiguous(), xyz.float(), seq_onehot.float(), aa_idx, mono)
 
 
 class RoseTTAFold(RFModule):
@@ -457,16 +468,21 @@ class RoseTTAFold(RFModule):
     def forward(self, msa, seq, aa_idx):
         if not msa.is_cuda:
             raise L.RfmiError("RoseTTAFold (MI355X build) needs device tensors; there is no CPU fallback")
-        m = self.msa_emb(msa, aa_idx)
-        p = self.pair_emb(seq, aa_idx)
-        onehot = torch.nn.functional.one_hot(seq, num_classes=21).float()
-        for blk in self.two_track_blocks:
-            p = blk.run(m, p)
-        xyz = self.initial_coord_generation_with_msa_and_pair.run(m, p, onehot, aa_idx)
-        for blk in self.three_track_blocks:
-            m, p, xyz = blk.run3(m, p, xyz, onehot, aa_idx)
-        m, p, xyz, plddt = self.final_block.run3(m, p, xyz, onehot, aa_idx)
-        logits = self.prediction_head(p)
+        with torch.cuda.device(msa.device):  # device guard: kernels go to the inputs' GPU, whatever the caller's current one
+            msa, seq, aa_idx = msa.contiguous(), seq.contiguous(), aa_idx.contiguous()
+            # the reference raises IndexError for out-of-range tokens / residue indices (nn.Embedding, rf.py:73,98)
+            mono = check_index_range(msa, seq, aa_idx, self.msa_emb.to_embedding.num_embeddings,
+                                     min(self.msa_emb.pos_enc.max_len, self.pair_emb.pos_enc.max_len))
+            m = self.msa_emb.run(msa, aa_idx)
+            p = self.pair_emb.run(seq, aa_idx)
+            onehot = ops.onehot(seq, 21)  # rf.py:1276
+            for blk in self.two_track_blocks:
+                p = blk.run(m, p)
+            xyz = self.initial_coord_generation_with_msa_and_pair.run(m, p, onehot, aa_idx)
+            for blk in self.three_track_blocks:
+                m, p, xyz = blk.run3(m, p, xyz, onehot, aa_idx, mono)
+            m, p, xyz, plddt = self.final_block.run3(m, p, xyz, onehot, aa_idx, mono)
+            logits = self.prediction_head.run(p)
         return logits, xyz, plddt
 
 

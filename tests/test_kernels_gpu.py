@@ -262,6 +262,89 @@ def test_tied_logits_softmax(B, H, N, Lr):
     assert torch.equal(sym, sym.transpose(1, 2))  # reference tests/test_module.py:406-413
 
 
+@pytest.mark.parametrize("B,H,N,Lr,weights", [(1, 2, 16, 64, True), (2, 3, 48, 128, True), (1, 12, 16, 192, False),
+                                              (2, 12, 128, 256, True), (1, 12, 128, 256, False)])
+def test_tied_attention_head_major(B, H, N, Lr, weights):
+    """The tied-attention core of the bench path (csrc/tied.hip): logits (+ in-kernel position weights) + softmax, the
+    symmetrised map and attention.V on head-major operands [B,N,3H,L,32], against the einsum formulas of rf.py:252-265
+    evaluated in fp32 on the same bf16 operands."""
+    dh = 32
+    D = H * dh
+    qkv = (randn(B, N, 3 * H, Lr, dh) * (0.9 / math.sqrt(math.sqrt(N)))).bfloat16()
+    q, k, v = qkv[:, :, :H], qkv[:, :, H:2 * H], qkv[:, :, 2 * H:]
+    w = torch.rand(B, H, N, Lr, device=DEV).softmax(2).contiguous() if weights else None
+    qs = 0.37
+    qf = q.float()
+    if weights:
+        qf = (qf * (w.permute(0, 2, 1, 3).unsqueeze(-1) * qs)).bfloat16().float()  # the kernel rounds q*w to bf16 (as the reference's bf16 run would)
+    ref_att = torch.einsum("bnhid,bnhjd->bhij", qf, k.float()).softmax(-1)
+    att = torch.empty(B, H, Lr, Lr, device=DEV, dtype=torch.bfloat16)
+    sym = torch.empty(B, Lr, Lr, H, device=DEV, dtype=torch.float32)
+    out = torch.empty(B, N, Lr, D, device=DEV, dtype=torch.bfloat16)
+    ops.tied_attention(q, k, v, out.view(B, N, Lr, H, dh).permute(0, 1, 3, 2, 4), att, w=w, qscale=qs if weights else 1.0, att_sym=sym)
+    assert rel_err(att, ref_att) < 1.5e-2
+    a = att.float()
+    assert rel_err(sym, (0.5 * (a + a.transpose(-1, -2))).permute(0, 2, 3, 1)) < 1e-6
+    ref_out = torch.einsum("bhij,bnhjd->bnihd", a, v.float()).reshape(B, N, Lr, D)  # A.V on the bf16 probabilities the kernel wrote
+    assert rel_err(out, ref_out) < 1e-2
+    # exact-integer check of the A.V indexing (row / column / key-order mix-ups show up exactly)
+    g = torch.Generator().manual_seed(3)
+    att_i = torch.randint(0, 3, (B, H, Lr, Lr), generator=g).to(DEV).bfloat16()
+    v_i = torch.randint(-2, 3, (B, N, H, Lr, dh), generator=g).to(DEV).bfloat16()
+    out_i = torch.empty(B, N, H, Lr, dh, device=DEV, dtype=torch.bfloat16)
+    from rosettafold_pytorch_amd._lib import lib, I64x4
+    import ctypes as C
+    vs = I64x4(*v_i.stride()[:4])
+    rc = lib.rf_tied_av(ops.ptr(att_i), ops.ptr(v_i), C.byref(vs), ops.ptr(out_i), C.byref(vs), B, H, N, Lr, dh, ops.stream())
+    assert rc == 0
+    ref_i = torch.einsum("bhij,bnhjd->bnhid", att_i.float(), v_i.float())
+    assert torch.equal(out_i.float(), ref_i.bfloat16().float())
+
+
+def test_tied_row_attention_functional_and_custom_op():
+    B, N, Lr, H, dh = 1, 16, 64, 4, 32
+    q, k, v = (randn(B, N, Lr, H, dh, seed=s_) * 0.4 for s_ in (0, 1, 2))
+    q, k, v = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    att = torch.einsum("bnihd,bnjhd->bhij", q.float(), k.float()).softmax(-1)
+    ref = torch.einsum("bhij,bnjhd->bnihd", att, v.float()).reshape(B, N, Lr, H * dh)
+    out, sym = ops.tied_row_attention(q, k, v)
+    assert rel_err(out, ref) < 2e-2 and rel_err(sym, (0.5 * (att + att.transpose(-1, -2))).permute(0, 2, 3, 1)) < 1.5e-2
+    import rosettafold_pytorch_amd.custom_ops  # noqa: F401  (registers torch.ops.rfmi.*)
+    out2, sym2 = torch.ops.rfmi.tied_row_attention(q, k, v)
+    assert torch.equal(out2, out) and torch.equal(sym2, sym)
+
+
+@pytest.mark.parametrize("B,N,Lr,D,H", [(2, 16, 8, 96, 12), (1, 128, 64, 384, 12), (2, 48, 20, 64, 1)])
+def test_poswise_collapsed(B, N, Lr, D, H):
+    """w[b,h,n,l] = softmax_n(scale * xn[b,n,l,:] . u[b,l,h,:]) on the matrix pipe vs the fp32 formula (rf.py:205-217)."""
+    xn = randn(B, N, Lr, D).bfloat16()
+    u = (randn(B, Lr, H, D, seed=1) * 0.3).bfloat16()
+    w = ops.poswise_collapsed(xn, u, 0.25)
+    ref = (torch.einsum("bnlc,blhc->bhnl", xn.float(), u.float()) * 0.25).softmax(2)
+    assert rel_err(w, ref) < 1e-4
+    assert (w.sum(2) - 1).abs().max() < 1e-5  # reference tests/test_module.py:180-200
+
+
+@pytest.mark.parametrize("N,BNexp", [(1152, 288), (768, 256), (576, 192), (384, 128)])
+def test_gemm_persistent_split_c(N, BNexp):
+    """Persistent GEMM with the split-C (head-major) epilogue: out[(b n), g, l, 32] from plain [M, K] x [N, K] operands;
+    exact on small integers, and equal to the generic kernel's split addressing."""
+    Lr, dh, K = 128, 32, 96
+    rows_bn, G = 128, N // dh
+    M = rows_bn * Lr
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-3, 4, (M, K), generator=g).to(DEV).bfloat16()
+    w = torch.randint(-3, 4, (N, K), generator=g).to(DEV).bfloat16()
+    b = torch.randint(-2, 3, (N,), generator=g).to(DEV).float()
+    out = torch.full((rows_bn, G, Lr, dh), 7.0, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(x, w, out, M, N, K, bias=b, c_row=(Lr, G * Lr * dh, dh), c_col=(dh, Lr * dh))
+    ref = (x.float() @ w.float().t() + b).view(rows_bn, Lr, G, dh).permute(0, 2, 1, 3)
+    assert torch.equal(out.float(), ref.bfloat16().float())
+    out2 = torch.empty_like(out)
+    ops.gemm(x, w, out2, M, N, K, bias=b, c_row=(Lr, G * Lr * dh, dh), c_col=(dh, Lr * dh), tile_cfg=1)  # generic kernel
+    assert torch.equal(out, out2)
+
+
 def test_gemm_block_layernorm_epilogue():
     """Outer-product GEMM with LayerNorm(1024) of every 32x32 output block in the epilogue (OuterProductMean, rf.py:416,
     424-426) against einsum + layer_norm; operands / output laid out exactly as the model's call."""

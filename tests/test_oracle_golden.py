@@ -157,3 +157,23 @@ def test_g1x1_gnorm_selfint(golden_dir):
     P, I, Y, _ = load(golden_dir, "gattentive_selfint")
     o = O.gattentive_selfint(pre(P, "m"), "m", {0: I["h0"], 1: I["h1"]}, {0: 4, 1: 3})
     close(o[0], Y["o0"]); close(o[1], Y["o1"])
+
+
+# ---- config-1-sized cases (B=1, N=8, L=64, d_msa=96, d_pair=64): the model's real head counts ----
+def load16(golden_dir, name):
+    P, I, Y, X = load(golden_dir, name)
+    return {k: v.float() for k, v in P.items()}, {k: v.float() for k, v in I.items()}, Y, X
+
+
+def test_c1_soft_tied_attention(golden_dir):
+    P, I, Y, X = load16(golden_dir, "c1_soft_tied_attention")
+    out, att = O.soft_tied_attention(pre(P, "m"), "m", I["x"], int(X["n_heads"]))
+    close(out, Y["out"])
+    close(att, Y["att"])
+
+
+def test_c1_pair_update_with_msa(golden_dir):
+    P, I, Y, X = load16(golden_dir, "c1_pair_update_with_msa")
+    s = int(X["stride"])
+    y = O.pair_update_with_msa(pre(P, "m"), "m", I["msa"], I["pair"], I["att"])
+    close(y[:, ::s, ::s], Y["y_sub2"], rtol=2e-4, atol=2e-5)
