@@ -319,6 +319,34 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
         // read back 16-byte chunks of consecutive columns and store whole lines
         char* const Cp = Cw + (int64_t)r0 * p.ldc * ESZ;
         const char* const Rp = HAS_RES ? Rw + (int64_t)r0 * p.ldc * 4 : nullptr;
+        if constexpr (CS) {
+          if (p.c_cc == 32) {
+            // head-major groups of 32 columns (csrc/tied.hip): one store instruction = the 64-byte pieces of 16 consecutive
+            // rows of ONE group = 1 KB of contiguous memory (consecutive rows of a group are adjacent in that layout)
+            const int r16 = lane >> 2, c4 = lane & 3;
+            const int abs0 = wn * (TN / 8);        // first 16-byte chunk column of this wave inside the tile
+            constexpr int NGI = (TN / 8 + 3) / 4 + ((TN / 8) % 4 ? 1 : 0);
+#pragma unroll
+            for (int gi = 0; gi < NGI; ++gi) {
+              const int absc = ((abs0 >> 2) + gi) * 4 + c4, cc = absc - abs0;
+              const bool okc = cc >= 0 && cc < TN / 8;
+#pragma unroll
+              for (int rr = 0; rr < (RP >= 16 ? RP / 16 : 1); ++rr) {
+                const int row = rr * 16 + r16;
+                if (okc && row < RP) {
+                  const f32x4 v = *(const f32x4*)(strip + row * PITCHW + cc * 16);
+                  const int m = m0 + wm * TM + r0 + row, n = n0 + absc * 8;
+                  f32x4* dst = (f32x4*)((char*)p.C + (cs_row(m) + (int64_t)(n >> 5) * p.c_co + (n & 31)) * ESZ);
+                  if (p.nt_store)
+                    __builtin_nontemporal_store(v, dst);
+                  else
+                    *dst = v;
+                }
+              }
+            }
+            continue;
+          }
+        }
 #pragma unroll
         for (int t0 = 0; t0 < NIT; t0 += G) {
           f32x4 res[G], vv[G];
@@ -447,7 +475,9 @@ int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
   if (d.bias_mode == RF_BIAS_COL && ((uintptr_t)d.bias % 16)) return 0;
   if (d.residual && (d.c_dtype != RF_F32 || ((uintptr_t)d.residual % 16))) return 0;
   if ((int64_t)256 * d.a_ri >= (1ll << 30) || (int64_t)64 * d.c_ri >= (1ll << 28)) return 0;  // 32-bit lane offsets
-  const int bn = d.N % 256 == 0 ? 256 : (d.N % 288 == 0 ? 288 : (d.N % 192 == 0 ? 192 : (d.N % 128 == 0 ? 128 : 0)));
+  // (split-C: the 288-wide tile is at the register limit already and its split epilogue spills into the K loop: 192 first)
+  const int bn = cs ? (d.N % 256 == 0 ? 256 : (d.N % 192 == 0 ? 192 : (d.N % 128 == 0 ? 128 : (d.N % 288 == 0 ? 288 : 0))))
+                    : (d.N % 256 == 0 ? 256 : (d.N % 288 == 0 ? 288 : (d.N % 192 == 0 ? 192 : (d.N % 128 == 0 ? 128 : 0))));
   if (!bn) return 0;
   FastP p;
   p.A = (const bf16_t*)d.A;

@@ -95,17 +95,11 @@ __global__ __launch_bounds__(256) void tied_logits_kernel(const TiedP p) {
   };
 
   if constexpr (SCALE) {
-    // w tile: rows it*64 .. +63 of every MSA row n (64 contiguous floats each); plain loads -> LDS, drained (loads and LDS
-    // writes) before the DMA prologue so the counted vmcnt of the main loop never has to cover them; the first step's
-    // barrier publishes the tile to the other waves.
-    const float* wb = p.w + (int64_t)b * p.w_b + (int64_t)h * p.w_h + it * 64;
-    float* wl = (float*)(smem + W_OFF);
-    for (int e = tid; e < p.N * 16; e += 256) {
-      const int n = e >> 4, c = e & 15;
-      const f32x4 v = *(const f32x4*)(wb + (int64_t)n * p.w_n + c * 4);
-      *(f32x4*)(wl + n * 64 + c * 4) = v * p.qscale;
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // w tile: rows it*64 .. +63 of every MSA row n (256 contiguous bytes each), by DMA: one instruction = 4 MSA rows.
+    // These are the oldest operations of every wave, so the counted wait of the first step covers them.
+    const float* wb = p.w + (int64_t)b * p.w_b + (int64_t)h * p.w_h + it * 64 + (lane & 15) * 4;
+    for (int i4 = wave; i4 * 4 < p.N; i4 += 4)
+      tied_glds16(wb + (int64_t)(i4 * 4 + (lane >> 4)) * p.w_n, smem + W_OFF + i4 * 1024);
   }
 
   f32x4 acc[JT];
@@ -130,7 +124,7 @@ __global__ __launch_bounds__(256) void tied_logits_kernel(const TiedP p) {
 #pragma unroll
     for (int j = 0; j < JT; ++j) kf[j] = *(const bf16x8*)(st + k_rd + j * 1024);
     if constexpr (SCALE) {
-      const float ws = wrow[n * 64];  // w[b,h,n, row of this lane] * d_head^-0.5: the same rounding point as q*w (rf.py:252)
+      const float ws = wrow[n * 64] * p.qscale;  // w[b,h,n, row of this lane] * d_head^-0.5: the same rounding point as q*w (rf.py:252)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         qf.u[e] = tpack2(__uint_as_float(qf.u[e] << 16) * ws, __uint_as_float(qf.u[e] & 0xffff0000u) * ws);
@@ -437,6 +431,7 @@ extern "C" int rf_tied_attention(const void* q, const void* k, const void* v, co
   for (int i = 0; i < 4; ++i)
     if (qk_strides[i] % 8) return RF_EALIGN;
   if (w && (((uintptr_t)w % 16) || w_strides[0] % 4 || w_strides[1] % 4 || w_strides[2] % 4)) return RF_EALIGN;
+  if (w && N % 4) return RF_EINVAL;  // the weight tile is staged four MSA rows per DMA instruction
   TiedP p;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k;
   p.b_stride = qk_strides[0]; p.n_stride = qk_strides[1]; p.h_stride = qk_strides[2]; p.l_stride = qk_strides[3];

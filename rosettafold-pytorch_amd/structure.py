@@ -160,7 +160,7 @@ class GSE3Res(nn.Module):
         return nets
 
     def _packed(self):
-        if self._rfc is None:
+        if not self._rfc:  # (None, or emptied by invalidate_weight_caches)
             nets = self._nets()
             with torch.no_grad():
                 pk = {
@@ -304,7 +304,7 @@ class CoordUpdateWithMsaAndPair(RFModule):
         return state, ops.coord_apply(xyz, out[1].contiguous())
 
     def forward(self, xyz, msa, pair, aa_idx, seq_onehot):
-        mono = check_index_range(None, None, aa_idx.contiguous(), 1, 1 << 62)
+        mono = check_index_range(None, None, aa_idx.contiguous(), 1, 2 ** 31 - 1)
         return self.run(xyz.float(), msa.float().contiguous(), pair.float().contiguous(), aa_idx, seq_onehot.float(),
                         monotonic=mono)
 
@@ -414,7 +414,7 @@ class ThreeTrackBlock(TwoTrackBlock):
 
     def forward(self, msa, pair, xyz, seq_onehot, aa_idx):
         msa = fresh_f32(msa)
-        mono = check_index_range(None, None, aa_idx.contiguous(), 1, 1 << 62)
+        mono = check_index_range(None, None, aa_idx.contiguous(), 1, 2 ** 31 - 1)
         return self.run3(msa, pair.float().contiguous(), xyz.float(), seq_onehot.float(), aa_idx, mono)
 
 
@@ -436,7 +436,7 @@ class FinalBlock(TwoTrackBlock):
 
     def forward(self, msa, pair, xyz, seq_onehot, aa_idx):
         msa = fresh_f32(msa)
-        mono = check_index_range(None, None, aa_idx.contiguous(), 1, 1 << 62)
+        mono = check_index_range(None, None, aa_idx.contiguous(), 1, 2 ** 31 - 1)
         return self.run3(msa, pair.float().contiguous(), xyz.float(), seq_onehot.float(), aa_idx, mono)
 
 

@@ -24,18 +24,21 @@ def _inputs():
     return msa, msa[:, 0].clone(), torch.arange(L).unsqueeze(0).repeat(B, 1)
 
 
-def _worker(rank, world, port, path):
+def _worker(rank, world, port, path, ckpt):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import rosettafold_pytorch_amd as R
     from rosettafold_pytorch_amd import shard
-    torch.manual_seed(1234)  # identical weights on every rank
-    model = R.RoseTTAFold(**CFG).to("cuda:0")
+    model = R.RoseTTAFold(**CFG)
+    R.load_checkpoint(model, ckpt)  # every rank loads the same checkpoint (CPU init is not thread-count invariant)
+    model = model.to("cuda:0")
     res = shard.forward_sharded(model, *_inputs(), dst=0)
     torch.cuda.synchronize()
     if rank == 0:
-        torch.save({"logits": {k: v.cpu() for k, v in res[0].items()}, "xyz": res[1].cpu(), "plddt": res[2].cpu()}, path)
+        torch.save({"logits": {k: v.cpu() for k, v in res[0].items()}, "xyz": res[1].cpu(), "plddt": res[2].cpu(),
+                    "weights": {k: v.double().sum().item() for k, v in model.state_dict().items()},
+                    "dtype": str(R.RT.dtype)}, path)
     else:
         assert res is None
     dist.barrier()
@@ -43,20 +46,25 @@ def _worker(rank, world, port, path):
 
 
 def test_forward_sharded_world2_matches_single_process(tmp_path):
-    path = str(tmp_path / "gathered.pt")
+    path, ckpt = str(tmp_path / "gathered.pt"), str(tmp_path / "weights.pt")
+    import rosettafold_pytorch_amd as R
+    torch.manual_seed(1234)
+    model = R.RoseTTAFold(**CFG)
+    R.save_checkpoint(model, ckpt)
+    model = model.to("cuda:0")
     ctx = mp.get_context("spawn")
     port = 33500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, path)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, path, ckpt)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(600)
         assert p.exitcode == 0
     got = torch.load(path)
-    import rosettafold_pytorch_amd as R
-    torch.manual_seed(1234)
-    model = R.RoseTTAFold(**CFG).to("cuda:0")
     msa, seq, aa = _inputs()
+    assert got["dtype"] == str(R.RT.dtype)
+    wdiff = [k for k, v in model.state_dict().items() if v.double().sum().item() != got["weights"][k]]
+    assert not wdiff, ("the ranks and this process initialised different weights", wdiff[:5])
     # single process, the same per-sample batches the ranks saw (a batch of 2 and a batch of 1)
     parts = [model(msa[lo:hi].cuda(), seq[lo:hi].cuda(), aa[lo:hi].cuda()) for lo, hi in ((0, 2), (2, 3))]
     for k in got["logits"]:
