@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- residues/s of the RoseTTAFold forward path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|1|4|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one forward of the full model (config 2 of BASELINE.json: B=4 MSAs of N=128 x L=256 per GPU,
-d_msa=384, d_pair=288, 8 two-track + 4 three-track + final block, 4 encoder layers) on synthetic token
-inputs already resident in HBM, random-init weights.  Independent MSAs shard across ranks (one process
-per GPU); the only collective is the gather of the results to rank 0 (RCCL), inside the timed region.
-Rank 0 prints ONE JSON line.  Extra legs on rank 0 at N=1:
-  * roofline: the dominant kernel family (the persistent bf16 MFMA GEMM of csrc/gemm_fast.hip) timed live with HIP events
-    around every launch of one extra profiled step; achieved = algorithmic FLOPs of those launches / their time.
-  * cpu_baseline: the CPU oracle (oracle/rf_oracle.py, a restatement pinned to the reference's golden vectors)
-    timed on the host cores on one block of each kind at config-2 shapes (B=1), scaled by the block counts.
+A "step" is one forward of the full model (config 2 = BASELINE.json configs[1]: B=4 MSAs of N=128 x L=256 per GPU,
+d_msa=384, d_pair=288, 8 two-track + 4 three-track + final block, 4 encoder layers) on synthetic token inputs already
+resident in HBM, random-init weights.  Independent MSAs shard across ranks (one process per GPU); the only collective is
+the gather of the results to rank 0 (RCCL), inside the timed region.  Rank 0 prints ONE JSON line.  Extra legs on rank 0
+at N=1:
+  * roofline: the dominant kernel family timed live with HIP events around every rf_gemm launch of one extra profiled
+    step (the library reports which kernel family each launch took: rf_gemm_last_family); achieved = algorithmic FLOPs of
+    those launches / their time.  `traffic` comes from the PMC file of THIS tree (profiles/r02_traffic_pmc.json carries a
+    hash of csrc/); a file collected on another tree is reported as stale and `traffic` stays null.
+  * parity: one forward of the SAME inputs in the exact-fp32 mode (the mode that carries the strict oracle parity,
+    tests/test_config2_gpu.py) -> agreement of the timed bf16 path with it: distogram argmax agreement, relative L2 of the
+    four logit maps / xyz / plddt, and the fp32-mode step time.
+  * cpu_baseline: the CPU oracle (oracle/rf_oracle.py, pinned to the reference's golden vectors) on the host cores: one
+    layer of each kind at the bench shapes (B=1), warm-up + best of 3, scaled by the layer counts.
+Other workloads: --config 4 (BASELINE.json configs[3]: B=1, N=64, L=1024) and --config 5 (configs[4]: the SE(3) structure
+module alone, B=8, L=256, k=128) print a JSON line of the same form (no roofline / cpu legs).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,21 +33,34 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FULL = dict(d_msa=384, d_pair=288, d_node=32, d_edge=32, d_state=32, n_two_track_blocks=8, n_three_track_blocks=5,
+            n_encoder_layers=4, n_neighbors=[128, 128, 64, 64, 64])
 CONFIGS = {
     # BASELINE.json configs[0] with the constructible d_msa: plumbing case
     1: dict(B=1, N=8, L=64, model=dict(d_msa=96, d_pair=64, d_node=8, d_edge=8, d_state=8, n_two_track_blocks=1,
                                        n_three_track_blocks=2, n_encoder_layers=1, max_len=64,
                                        n_neighbors=[128, 128])),
     # configs[1]: the configuration the metric is quoted on (README hyper-parameters of the reference)
-    2: dict(B=4, N=128, L=256, model=dict(d_msa=384, d_pair=288, d_node=32, d_edge=32, d_state=32,
-                                          n_two_track_blocks=8, n_three_track_blocks=5, n_encoder_layers=4,
-                                          max_len=260, n_neighbors=[128, 128, 64, 64, 64])),
-    # configs[3]: long-sequence stress (not the metric's configuration; `--config 4` for a manual run)
-    4: dict(B=1, N=64, L=1024, model=dict(d_msa=384, d_pair=288, d_node=32, d_edge=32, d_state=32,
-                                          n_two_track_blocks=8, n_three_track_blocks=5, n_encoder_layers=4,
-                                          max_len=1030, n_neighbors=[128, 128, 64, 64, 64])),
+    2: dict(B=4, N=128, L=256, model=dict(FULL, max_len=260)),
+    # configs[3]: long-sequence stress
+    4: dict(B=1, N=64, L=1024, model=dict(FULL, max_len=1030)),
+    # configs[4]: SE(3) structure-module-only microbench (CoordUpdateWithMsaAndPair, k = 128)
+    5: dict(B=8, N=16, L=256, model=dict(FULL, max_len=260)),
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+FAMILY = {0: "gemm_f32_kernel (fp32 MFMA 16x16x4)", 1: "gemm_bf16_kernel (MFMA 16x16x32)",
+          2: "gemm_bf16_kernel<conv3x3> (MFMA 16x16x32)", 3: "gemm_fast_kernel (persistent tiles, MFMA 16x16x32)",
+          4: "gemm_wreg_kernel (register-resident weights, MFMA 16x16x32)"}
+
+
+def tree_hash():
+    """Identifies the kernel sources a PMC collection belongs to."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "rosettafold-pytorch_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
 
 
 def make_inputs(B, N, L, seed, device):
@@ -55,6 +76,7 @@ def profile_gemms(model, inputs):
     from rosettafold_pytorch_amd import ops
     recs = []
     orig = ops.lib.rf_gemm
+    fam_of = ops.lib.rf_gemm_last_family
 
     def wrapped(desc, stream):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -67,12 +89,7 @@ def profile_gemms(model, inputs):
         k_eff = d.K // 9 if d.a_mode == 1 else d.K  # conv: the image is read once algorithmically
         nbytes = nb * (d.M * k_eff * esz + d.N * d.K * esz + d.M * d.N * (4 if d.c_dtype == 0 else 2)
                        + (d.M * d.N * 4 if d.residual else 0))
-        # same predicate as rf_gemm_fast_try (csrc/gemm_fast.hip): plain row-major panels go to the persistent kernel
-        fast = (d.ab_dtype == 1 and d.a_mode == 0 and nb == 1 and d.a_rc <= 0 and d.b_rc <= 0 and d.c_rc <= 0 and d.c_cc <= 0
-                and d.M % 256 == 0 and d.M >= 16384 and d.K >= 64 and d.alpha == 1.0 and d.tile_cfg == 0
-                and (d.N % 256 == 0 or d.N % 288 == 0 or d.N % 192 == 0 or d.N % 128 == 0) and d.bias_mode != 2 and d.act in (0, 1)
-                and not d.ln_out and (d.kc <= 0 or d.kc == d.K))
-        recs.append((s, e, 2.0 * d.M * d.N * d.K * nb, d.ab_dtype, d.M, d.N, d.K, nb, d.a_mode, nbytes, fast))
+        recs.append((s, e, 2.0 * d.M * d.N * d.K * nb, int(fam_of()), d.M, d.N, d.K, nb, nbytes))
         return rc
 
     ops.lib.rf_gemm = wrapped
@@ -83,38 +100,62 @@ def profile_gemms(model, inputs):
         ops.lib.rf_gemm = orig
     if os.environ.get("RF_GEMM_TABLE"):
         tab = {}
-        for s, e, fl, dt, M, N, K, nb, amode, _, _f in recs:
-            t = tab.setdefault((dt, amode, M, N, K, nb), [0.0, 0.0, 0])
+        for s, e, fl, fam, M, N, K, nb, _ in recs:
+            t = tab.setdefault((fam, M, N, K, nb), [0.0, 0.0, 0])
             t[0] += s.elapsed_time(e)
             t[1] += fl
             t[2] += 1
         for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])[:40]:
-            log("gemm dt=%d conv=%d M=%d N=%d K=%d batch=%d : %d calls %.2f ms total, %.0f TF/s" % (*k, v[2], v[0], v[1] / v[0] / 1e9))
+            log("gemm family=%d M=%d N=%d K=%d batch=%d : %d calls %.2f ms total, %.0f TF/s" % (*k, v[2], v[0], v[1] / v[0] / 1e9))
     fams = {}
-    for s, e, fl, dt, M, N, K, nb, amode, nbytes, fast in recs:
-        if dt != 1:
-            fam = "gemm_f32_kernel (fp32 MFMA 16x16x4)"
-        elif amode == 1:
-            fam = "gemm_bf16_kernel<conv3x3> (MFMA 16x16x32)"
-        elif fast:
-            fam = "gemm_fast_kernel (persistent, MFMA 16x16x32)"
-        else:
-            fam = "gemm_bf16_kernel (MFMA 16x16x32)"
-        f = fams.setdefault(fam, [0.0, 0.0, 0, 0.0])
+    for s, e, fl, fam, M, N, K, nb, nbytes in recs:
+        f = fams.setdefault(FAMILY.get(fam, f"family {fam}"), [0.0, 0.0, 0, 0.0])
         f[0] += s.elapsed_time(e) * 1e-3
         f[1] += fl
         f[2] += 1
         f[3] += nbytes
-    return fams, sum(r[0].elapsed_time(r[1]) for r in recs) * 1e-3
+    return fams
 
 
 def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def parity_block(model, inputs, out_bf16, R, steps=2):
+    """The timed bf16 path against the exact-fp32 mode of the same library on the same inputs and weights."""
+    R.set_compute_dtype(torch.float32)
+    try:
+        lg, xyz, pl = model(*inputs)  # warm-up (weight copies of this mode)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            lg, xyz, pl = model(*inputs)
+        torch.cuda.synchronize()
+        ms32 = 1e3 * (time.perf_counter() - t0) / steps
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    lb, xb, pb = out_bf16
+    agree = {k: (lb[k].argmax(-1) == lg[k].argmax(-1)).float().mean().item() for k in lg}
+    # margin-aware view: bins whose top-2 fp32 logits are further apart than 2 % of the map's range cannot flip by rounding
+    d = lg["dist"]
+    top2 = d.topk(2, -1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 0.02 * (d.max() - d.min())
+    agree_clear = (lb["dist"].argmax(-1) == d.argmax(-1))[clear].float().mean().item() if clear.any() else None
+    return {"reference_mode": "exact fp32 kernels of the same library (the mode the oracle tests pin: tests/test_config2_gpu.py)",
+            "dist_argmax_agreement": agree["dist"], "argmax_agreement": agree,
+            "dist_argmax_agreement_clear_margin": agree_clear, "clear_margin_fraction": clear.float().mean().item(),
+            "rel_l2": {**{k: rel_l2(lb[k], lg[k]) for k in lg}, "xyz": rel_l2(xb, xyz), "plddt": rel_l2(pb, pl)},
+            "fp32_mode_ms_per_step": ms32}
+
+
 def cpu_baseline(cfg):
-    """Oracle timed on the host cores, bounded: ONE layer of each kind at the bench shapes with B=1 (every block
-    repeats the same layers), scaled by the layer counts of the full model."""
+    """Oracle timed on the host cores, bounded: ONE layer of each kind at the bench shapes with B=1 (every block repeats
+    the same layers), warm-up + best of 3, scaled by the layer counts of the full model."""
     from oracle import rf_oracle as O
     import rosettafold_pytorch_amd as R
     mc, N, L = cfg["model"], cfg["N"], cfg["L"]
@@ -152,19 +193,38 @@ def cpu_baseline(cfg):
     t = {}
     with torch.no_grad():
         for name, fn in pieces.items():
-            t0 = time.perf_counter()
-            fn()
-            t[name] = time.perf_counter() - t0
-            log(f"cpu oracle {name}: {t[name]:.2f}s")
+            fn()  # warm-up (allocator, MKL thread pools)
+            best = float("inf")
+            for _ in range(3):
+                t0 = time.perf_counter()
+                fn()
+                best = min(best, time.perf_counter() - t0)
+            t[name] = best
+            log(f"cpu oracle {name}: best of 3 {t[name]:.2f}s")
     n2, n3, ne = mc["n_two_track_blocks"], mc["n_three_track_blocks"], mc["n_encoder_layers"]
     nb = n2 + n3
     full = (nb * (ne * (t["msa_row_layer"] + t["msa_col_layer"] + t["pair_axial_layer"] + t["msa_with_pair_layer"])
                   + t["pair_update_with_msa"]) + t["init_coord"] + n3 * t["coord_update"] + (n3 - 1) * t["msa_with_coord"]
             + t["head"])
     return {"value": L / full, "unit": "residues/s", "cores": ncores, "kind": "port",
-            "sample": "B=1,N=%d,L=%d, one layer of each kind timed once (%s) = %.1fs of CPU work; scaled by the layer "
-                      "counts of the %d+%d-block model -> %.0fs/sample" % (
+            "sample": "B=1,N=%d,L=%d, one layer of each kind, warm-up + best of 3 (%s) = %.1fs of CPU work per pass; scaled by "
+                      "the layer counts of the %d+%d-block model -> %.0fs/sample" % (
                           N, L, ", ".join(f"{k} {v:.2f}s" for k, v in t.items()), sum(t.values()), n2, n3, full)}
+
+
+def se3_inputs(cfg, dev, seed):
+    B, N, L, mc = cfg["B"], cfg["N"], cfg["L"], cfg["model"]
+    g = torch.Generator().manual_seed(seed)
+    steps = torch.randn(B, L, 3, generator=g)
+    ca = torch.cumsum(3.8 * steps / steps.norm(dim=-1, keepdim=True), 1)
+    xyz = ca[:, :, None, :] + 0.5 * torch.randn(B, L, 3, 3, generator=g)
+    xyz[:, :, 1] = ca
+    msa = torch.randn(B, N, L, mc["d_msa"], generator=g)
+    pair = torch.randn(B, L, L, mc["d_pair"], generator=g)
+    seq = torch.randint(0, 21, (B, L), generator=g)
+    oh = torch.nn.functional.one_hot(seq, 21).float()
+    aa = torch.arange(L).unsqueeze(0).repeat(B, 1)
+    return [t.to(dev) for t in (xyz, msa, pair, aa, oh)]
 
 
 def main():
@@ -176,34 +236,43 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)  # before the process group: RCCL binds its communicator to the current device
+    dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
-    local = local % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
 
     import rosettafold_pytorch_amd as R
     cfg = CONFIGS[args.config]
     R.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     torch.manual_seed(1234)  # identical weights on every rank
-    model = R.RoseTTAFold(p_dropout=0.0, **cfg["model"]).to(dev)
     B, N, L = cfg["B"], cfg["N"], cfg["L"]
-    inputs = make_inputs(B, N, L, seed=rank, device=dev)  # independent MSAs per rank
+    if args.config == 5:
+        mc = cfg["model"]
+        model = R.CoordUpdateWithMsaAndPair(mc["d_msa"], mc["d_pair"], mc["d_node"], mc["d_edge"], mc["d_state"],
+                                            n_neighbors=128, p_dropout=0.0).to(dev)
+        inputs = se3_inputs(cfg, dev, seed=rank)
+        run = lambda: model.run(*inputs)  # noqa: E731
+    else:
+        model = R.RoseTTAFold(p_dropout=0.0, **cfg["model"]).to(dev)
+        inputs = make_inputs(B, N, L, seed=rank, device=dev)  # independent MSAs per rank
+        run = lambda: model(*inputs)  # noqa: E731
 
     def step():
-        logits, xyz, plddt = model(*inputs)
-        if world > 1:  # the one collective of the path: gather the results on rank 0 (RCCL over xGMI)
+        out = run()
+        if world > 1 and args.config != 5:  # the one collective of the path: gather the results on rank 0 (RCCL over xGMI)
             from rosettafold_pytorch_amd import shard
-            shard.gather_results(logits, xyz, plddt, dst=0)
-        return logits
+            shard.gather_results(out[0], out[1], out[2], dst=0)
+        return out
 
     def fence():
         if world > 1:
@@ -219,7 +288,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        out = step()
     fence()
     dt = time.perf_counter() - t0
     if rank == 0:
@@ -231,32 +300,41 @@ def main():
         dt = tt.item()
 
     if rank == 0:
-        out = {
+        mc = cfg["model"]
+        if args.config == 5:
+            workload = (f"BASELINE.json configs[4]: SE(3) structure module only (CoordUpdateWithMsaAndPair), bsz={B}/GPU, L={L}, "
+                        f"n_neighbors=128, d_node=d_edge=d_state=32")
+        else:
+            workload = (f"BASELINE.json configs[{args.config - 1}]: bsz={B}/GPU, n_seq={N}, L={L}, d_msa={mc['d_msa']}, "
+                        f"d_pair={mc['d_pair']}, {mc['n_two_track_blocks']}+{mc['n_three_track_blocks']} blocks, "
+                        f"{mc['n_encoder_layers']} encoder layers, random-init weights")
+        res = {
             "metric": f"residues/sec forward (L={L}, N={N})", "value": world * B * L * args.steps / dt,
             "unit": "residues/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{args.config - 1}]: bsz={B}/GPU, n_seq={N}, L={L}, "
-                                   f"d_msa={cfg['model']['d_msa']}, d_pair={cfg['model']['d_pair']}, "
-                                   f"{cfg['model']['n_two_track_blocks']}+{cfg['model']['n_three_track_blocks']} blocks, "
-                                   f"{cfg['model']['n_encoder_layers']} encoder layers, random-init weights",
-                       "global_batch": world * B, "parallelism": f"batch-sharded x{world} (replicated weights)"},
+            "config": {"workload": workload, "global_batch": world * B,
+                       "parallelism": f"batch-sharded x{world} (replicated weights)"},
         }
-        if world == 1 and not args.no_roofline:
-            fams, tot = profile_gemms(model, inputs)
+        full = args.config == 2 and args.dtype == "bf16"
+        if world == 1 and full and not args.no_roofline:
+            fams = profile_gemms(model, inputs)
             name, (secs, flops, n, nbytes) = max(fams.items(), key=lambda kv: kv[1][0])
-            traffic = None  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_traffic_pmc.json)
+            traffic, tnote = None, "no PMC collection for this tree (tools/pmc_traffic.py)"
             try:
-                with open(os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")) as fh:
-                    pm = json.load(fh)["families"]
-                key = name.split(" ")[0]
-                traffic = pm[key]["hbm_bytes_per_launch"]
+                with open(os.path.join(ROOT, "profiles", "r02_traffic_pmc.json")) as fh:
+                    pm = json.load(fh)
+                if pm.get("tree") == tree_hash():
+                    traffic = pm["families"][name.split(" ")[0]]["hbm_bytes_per_launch"]
+                    tnote = f"rocprofv3 PMC passes (FETCH_SIZE x2, WRITE_SIZE) on this tree ({pm['tree']})"
+                else:
+                    tnote = f"stale: profiles/r02_traffic_pmc.json was collected on tree {pm.get('tree')}, this is {tree_hash()}"
             except (OSError, KeyError, ValueError):
                 pass
-            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": flops / secs / 1e12,
+            res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": flops / secs / 1e12,
                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": flops / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
-                               "launches": n, "avg_launch_ms": 1e3 * secs / n,
+                               "traffic_source": tnote, "launches": n, "avg_launch_ms": 1e3 * secs / n,
                                "algorithmic_gflop_per_launch": flops / n / 1e9,
                                "algorithmic_bytes_per_launch": nbytes / n,
                                "algorithmic_hbm_GBps": nbytes / secs / 1e9, "hbm_peak_GBps": 8000.0,
@@ -264,9 +342,11 @@ def main():
                                "families": {k: {"s": v[0], "tflops": v[1] / max(v[0], 1e-12) / 1e12, "n": v[2],
                                                 "algorithmic_GBps": v[3] / max(v[0], 1e-12) / 1e9}
                                             for k, v in fams.items()}}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out), flush=True)
+        if world == 1 and full and not args.no_parity:
+            res["parity"] = parity_block(model, inputs, out, R)
+        if world == 1 and full and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(res), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -91,6 +91,9 @@ typedef struct rf_gemm_desc {
 } rf_gemm_desc;
 
 int rf_gemm(const rf_gemm_desc* d, void* stream);
+/* Introspection for measurement tools: the kernel family the calling thread's last rf_gemm launched (0 exact fp32, 1 generic
+ * bf16 tile kernel, 2 conv3x3 implicit GEMM, 3 persistent tile kernel, 4 register-resident-weights skinny-K kernel, -1 none). */
+int rf_gemm_last_family(void);
 
 /* LayerNorm over the last dim (nn.LayerNorm, rf.py:323,328,416,435,437,442,443,565,573,580,672,
  * 685,686,758,759,765,771,876,877,883,886,1136; ea/modules.py:553).  rows x D, fp32 statistics. */

@@ -83,6 +83,7 @@ PROTOTYPES = {
     "rf_add_pos_enc": [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "rf_debug_gemm_stamps": [vp],
     "rf_debug_gemm_fast_stamps": [vp],
+    "rf_gemm_last_family": [],
     "rf_version": [],
 }
 

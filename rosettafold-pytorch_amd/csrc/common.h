@@ -80,4 +80,6 @@ static inline bool rf_env_flag(const char* name) { return getenv(name) != nullpt
 
 // gemm_fast.hip: persistent plain-layout bf16 GEMM; returns 1 (launched, *rc = status) or 0 (descriptor does not fit)
 int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream);
+// gemm_wreg.hip: skinny-K (K = 288 / 384) projection GEMM with register-resident weights; same return convention
+int rf_gemm_wreg_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream);
 void rf_gemm_fast_set_stamps(void* buf);

@@ -696,7 +696,14 @@ extern "C" int rf_debug_gemm_fast_stamps(void* buf) {
   return 0;
 }
 
+// Which kernel family the calling thread's last rf_gemm chose (bench.py attributes launch times with it instead of
+// re-deriving the dispatch rules): 0 exact-fp32, 1 generic bf16 tile, 2 conv3x3 implicit GEMM, 3 persistent tile kernel
+// (gemm_fast.hip), 4 register-resident-weights kernel (gemm_wreg.hip); -1 = nothing launched.
+static thread_local int g_last_family = -1;
+extern "C" int rf_gemm_last_family(void) { return g_last_family; }
+
 extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
+  g_last_family = -1;
   if (!dd || !dd->A || !dd->B || !dd->C) return RF_EINVAL;
   GemmP p;
   p.d = *dd;
@@ -762,6 +769,7 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
     const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
     if (nblk > 0x7fffffffLL) return RF_EINVAL;
     hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)nblk), dim3(256), 0, s, p);
+    g_last_family = 0;
     return rf_launch_status();
   }
   if (d.ab_dtype != RF_BF16) return RF_EINVAL;
@@ -787,11 +795,19 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   }
   if (d.tile_cfg == 0 && !p.dbg && !p.stamps) {  // (stamps of the generic kernel: keep it on the generic kernel)
     int rc = 0;
-    if (rf_gemm_fast_try(d, batch, &rc, stream)) return rc;
+    if (rf_gemm_wreg_try(d, batch, &rc, stream)) {
+      g_last_family = 4;
+      return rc;
+    }
+    if (rf_gemm_fast_try(d, batch, &rc, stream)) {
+      g_last_family = 3;
+      return rc;
+    }
     if (want_ln) {
       rf_gemm_desc d2 = d;
       d2.ln_out = nullptr;
       if (rf_gemm_fast_try(d2, batch, &rc, stream)) {
+        g_last_family = 3;
         if (rc != 0) return rc;
         return rf_layernorm(d.C, RF_F32, d.c_ri, d.ln_out, RF_BF16, d.N, d.M, d.N, d.ln_gamma, d.ln_beta, d.ln_eps, 1, RF_ACT_NONE, stream);
       }
@@ -848,6 +864,7 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   RF_CASE(256, 128, 32, 2, 2)
   RF_CASE(128, 256, 32, 2, 2)
 #undef RF_CASE
+  g_last_family = d.a_mode == RF_AMODE_CONV3X3 ? 2 : 1;
   if (rc != 0 || !want_ln) return rc;
   return rf_layernorm(d.C, RF_F32, d.c_ri, d.ln_out, RF_BF16, d.N, d.M, d.N, d.ln_gamma, d.ln_beta, d.ln_eps, 1, RF_ACT_NONE, stream);
 }

@@ -31,6 +31,8 @@ struct FastP {
   int tilesN, ntiles;
   int nt_store;
   int no_lag;  // experiment switch: 1 = waves 4-7 run the same phase order as waves 0-3
+  int dbg;     // timing experiments (RF_GEMM_DBG, results are WRONG when set): 1 skip MFMAs, 2 skip the DMA of every K step but
+               // a tile's first, 4 skip the epilogue's global stores / residual loads, 8 skip the fragment reads
   // fused "LayerNorm of the next sub-layer" (LN variant: N == BN, fp32 C with residual): bf16 [M, N] normalised rows
   void* ln_out;
   const float* ln_gamma;
@@ -174,8 +176,9 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
     //   waves 0-3:  R0 M0 R1 M1 | R0 M0 R1 M1 |        waves 4-7:  M1' R0 M0 R1 | M1' R0 M0 R1 | ... M1'
     // (one barrier per K step as before; the carried fragments are in registers, and a lagging wave retires its R1 reads
     // before the barrier, so the buffer can be re-staged right behind it).
-    bf16x8 af[WM], bfr[WN];
+    bf16x8 af[WM] = {}, bfr[WN] = {};
     auto read_frags = [&](int kk) {
+      if (p.dbg & 8) return;
       const char* a_lds = smem + buf * STAGE_BYTES;
       const char* b_lds = a_lds + A_BYTES;
 #pragma unroll
@@ -190,6 +193,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
       }
     };
     auto mfmas = [&]() {
+      if (p.dbg & 1) return;
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -204,9 +208,9 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
       if constexpr (STAMP) { const unsigned long long t = clock64(); tk_vm += t - tk_x; tk_x = t; }
       __syncthreads();
       if constexpr (STAMP) { const unsigned long long t = clock64(); tk_bar += t - tk_x; tk_x = t; }
-      if (kt + 1 < nk)
-        stage(buf ^ 1, m0, n0, kt + 1);
-      else if (has_next)
+      if (kt + 1 < nk) {
+        if (!(p.dbg & 2)) stage(buf ^ 1, m0, n0, kt + 1);
+      } else if (has_next)
         stage(buf ^ 1, m0n, n0n, 0);
       const bool second = !(half_tail && kt == nk - 1);
       if constexpr (LAG) {
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
           for (int g = 0; g < G; ++g) {
             if constexpr (HAS_RES && !LN) {
               res[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-              if (t0 + g < NIT && (NCH % 64 == 0 || lane + 64 * (t0 + g) < NCH)) res[g] = *(const f32x4*)(Rp + (unsigned)goff[t0 + g] * 4u);
+              if (t0 + g < NIT && (NCH % 64 == 0 || lane + 64 * (t0 + g) < NCH) && !(p.dbg & 4)) res[g] = *(const f32x4*)(Rp + (unsigned)goff[t0 + g] * 4u);
             }
           }
 #pragma unroll
@@ -372,6 +376,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
             } else {
               dst = (f32x4*)(Cp + (unsigned)goff[t0 + g] * (unsigned)ESZ);
             }
+            if (p.dbg & 4) continue;
             if (p.nt_store)
               __builtin_nontemporal_store(v, dst);
             else
@@ -497,6 +502,8 @@ int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
   const bool f32 = d.c_dtype == RF_F32, res = d.residual != nullptr;
   p.stamps = g_fast_stamps;
   p.no_lag = no_lag;
+  static const int dbg = getenv("RF_GEMM_DBG") ? atoi(getenv("RF_GEMM_DBG")) : 0;
+  p.dbg = dbg;
   p.ln_out = d.ln_out; p.ln_gamma = d.ln_gamma; p.ln_beta = d.ln_beta; p.ln_eps = d.ln_eps;
   p.c_rc = d.c_rc; p.c_cc = d.c_cc; p.c_ro = d.c_ro; p.c_co = d.c_co;
   p.c_rsh = (d.c_rc > 0 && (d.c_rc & (d.c_rc - 1)) == 0) ? __builtin_ctz(d.c_rc) : -1;

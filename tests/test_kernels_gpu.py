@@ -62,6 +62,48 @@ def test_gemm_persistent_fast_path(M, N, K):
     assert rel_err(y, y2) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(16384, 256, 288), (16384 + 192, 1536, 288), (16384, 1152, 288), (32768, 384, 288),
+                                   (16384, 256, 384), (16384 + 64, 2304, 384), (16384, 1152, 384), (16384, 128 * 5, 384)])
+def test_gemm_wreg_skinny_k(M, N, K):
+    """K = 288 / 384 projections take the register-resident-weights kernel (gemm_wreg.hip): exact on small integers (any
+    row / column / K-slot / swizzle mix-up shows up exactly), bias + ReLU, random data vs fp32, ragged row-tile counts."""
+    from rosettafold_pytorch_amd._lib import lib
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(-3, 4, (M, K), generator=g).to(DEV).bfloat16()
+    w = torch.randint(-3, 4, (N, K), generator=g).to(DEV).bfloat16()
+    b = torch.randint(-4, 5, (N,), generator=g).to(DEV).float()
+    y = ops.linear(x, w, None, out_dtype=torch.bfloat16)
+    assert lib.rf_gemm_last_family() == 4
+    ref = x.float() @ w.float().t()
+    assert torch.equal(y.float(), ref.bfloat16().float())
+    y = ops.linear(x, w, b, out_dtype=torch.bfloat16, act=L.ACT_RELU)
+    assert torch.equal(y.float(), torch.relu(ref + b).bfloat16().float())
+    xr, wr = randn(M, K, dtype=torch.bfloat16), randn(N, K, dtype=torch.bfloat16, seed=1)
+    y = ops.linear(xr, wr, b, out_dtype=torch.bfloat16)
+    assert rel_err(y, xr.float() @ wr.float().t() + b) < 2e-2
+    y2 = ops.linear(xr, wr, b, out_dtype=torch.bfloat16, tile_cfg=1)  # generic kernel on the same operands
+    assert lib.rf_gemm_last_family() == 1
+    assert rel_err(y, y2.float()) < 1e-2
+
+
+@pytest.mark.parametrize("K", [288, 384])
+def test_gemm_wreg_split_c(K):
+    """The head-major (split-C) output of the skinny-K kernel: [rows/L, G, L, 32] from plain operands, exact."""
+    from rosettafold_pytorch_amd._lib import lib
+    Lr, dh, N = 128, 32, 1152
+    rows_bn, G = 128, N // dh
+    M = rows_bn * Lr
+    g = torch.Generator().manual_seed(6)
+    x = torch.randint(-3, 4, (M, K), generator=g).to(DEV).bfloat16()
+    w = torch.randint(-3, 4, (N, K), generator=g).to(DEV).bfloat16()
+    b = torch.randint(-2, 3, (N,), generator=g).to(DEV).float()
+    out = torch.full((rows_bn, G, Lr, dh), 7.0, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(x, w, out, M, N, K, bias=b, c_row=(Lr, G * Lr * dh, dh), c_col=(dh, Lr * dh))
+    assert lib.rf_gemm_last_family() == 4
+    ref = (x.float() @ w.float().t() + b).view(rows_bn, Lr, G, dh).permute(0, 2, 1, 3)
+    assert torch.equal(out.float(), ref.bfloat16().float())
+
+
 def test_gemm_persistent_exact_integers():
     """Small-integer operands: any row / column / K-chunk mix-up of the persistent kernel shows up exactly."""
     M, N, K = 16384, 288, 136

@@ -185,7 +185,8 @@ def test_knn_graph_bit_exact(k):
     xyz = xyz_trace(B, Lr)
     edge = rn(B, Lr, Lr, DE)
     g = S.build_graph(xyz.to(DEV), edge.to(DEV), AA.to(DEV), k)
-    n = int(g["count"].item())
+    n = int(g["count"][0].item())
+    assert int(g["count"][1].item()) == n  # no edge dropped: the capacity bound held
     b, i, j = O.knn_graph(xyz, AA, k)
     assert n == b.numel() and n <= g["cap"]
     assert torch.equal(g["src"][:n].cpu().long(), b * Lr + i) and torch.equal(g["dst"][:n].cpu().long(), b * Lr + j)

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun) from the repo root: kernel-trace statistics + the two PMC passes of one bench forward,
+# summaries copied next to the other gpurun_out files (copy the ones to keep into profiles/ afterwards).
+#   bash tools/collect_profiles.sh <tag>
+set -u
+TAG=${1:-r02}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_$TAG
+rm -rf "$OUT"; mkdir -p "$OUT"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity > "$OUT/stats.log" 2>&1
+find "$OUT/stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "gpurun_out/${TAG}_kernel_stats_bench_config2.csv"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-parity > "$OUT/fetch.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-parity > "$OUT/write.log" 2>&1
+python3 tools/pmc_traffic.py "$OUT/fetch" "$OUT/write" "gpurun_out/${TAG}_traffic_pmc.json" > "gpurun_out/${TAG}_traffic_pmc.log" 2>&1
+# drop the bulky raw traces (only the summaries travel back)
+rm -rf "$OUT/stats" "$OUT/fetch" "$OUT/write"
+tail -3 "$OUT/stats.log"; cat "gpurun_out/${TAG}_traffic_pmc.log"

@@ -15,6 +15,14 @@ import sys
 def family(name):
     if name.startswith("void gemm_fast_kernel") or name.startswith("gemm_fast_kernel"):
         return "gemm_fast_kernel"
+    if "gemm_wreg_kernel" in name:
+        return "gemm_wreg_kernel"
+    if "tied_logits_kernel" in name:
+        return "tied_logits_kernel"
+    if "tied_av_kernel" in name:
+        return "tied_av_kernel"
+    if "outer_fused_kernel" in name:
+        return "outer_fused_kernel"
     if "gemm_bf16_kernel" in name:
         return "gemm_bf16_kernel<conv3x3>" if name.rstrip(">(GemmP) ").endswith(", 1") or ", 1>(GemmP)" in name else "gemm_bf16_kernel"
     if "gemm_f32_kernel" in name:
@@ -56,6 +64,16 @@ def read_durations(d):
     return tot, n
 
 
+def tree_hash():
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rosettafold-pytorch_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def main():
     fd, wd, out = sys.argv[1:4]
     fs, fc = read_counter(fd, "FETCH_SIZE")
@@ -67,11 +85,11 @@ def main():
         wr = ws.get(fam, 0.0) * 1024 / nl
         fams[fam] = {"launches": nl, "FETCH_SIZE_KB_sum": fs.get(fam, 0.0), "WRITE_SIZE_KB_sum": ws.get(fam, 0.0),
                      "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr}
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of `python bench.py --steps 1 "
-                       "--warmup 0 --no-cpu-baseline --no-roofline` (config 2, B=4); KB units; FETCH_SIZE doubled per "
+    json.dump({"tree": tree_hash(), "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of `python bench.py --steps 1 "
+                       "--warmup 0 --no-cpu-baseline --no-roofline --no-parity` (config 2, B=4); KB units; FETCH_SIZE doubled per "
                        "MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced stream); per-launch averages over every "
                        "launch of the family in one forward (kernels run serialised under --pmc, so durations are not taken "
-                       "from these passes)",
+                       "from these passes); `tree` = sha1 of csrc/*.hip|*.h at collection time (bench.py refuses a stale file)",
                "families": fams}, open(out, "w"), indent=1)
     for k, v in fams.items():
         print(k, v["launches"], f"{v['hbm_bytes_per_launch'] / 1e6:.1f} MB/launch (read {v['hbm_read_bytes_per_launch'] / 1e6:.1f}, write {v['hbm_write_bytes_per_launch'] / 1e6:.1f})")
