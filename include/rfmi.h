@@ -152,6 +152,19 @@ int rf_tied_attention(const void* q, const void* k, const void* v, const int64_t
 int rf_poswise_collapsed(const void* xn, const void* u, float* w, int B, int N, int L, int D, int H, float scale,
                          void* stream);
 
+/* Fused OuterProductMean (rf.py:412-427): out[b,i,j,:] = Linear(LayerNorm_1024(sum_n x[b,n,i,:] (x) y[b,n,j,:])) in one
+ * kernel; the 1024-wide feature tensor never exists in HBM.  xt / yt: bf16 [B, L, 32, N] (MSA depth contiguous);
+ * wprime: bf16 [Dout, 1024] = W * gamma (LayerNorm affine folded in); s[o] = sum_k wprime[o,k] (fp32, of the bf16 values);
+ * c[o] = sum_k W[o,k] beta[k] + bias[o]; out: fp32 [B, L, L, Dout]:
+ *     out = rstd * (sum_k co_k wprime[o,k] - mean * s[o]) + c[o],   mean / rstd over the 1024 features in fp32.
+ * Supported: P == 32, Dout == 288, N in {64, 128}, L % 16 == 0 (RF_EINVAL otherwise: rf_gemm with RF_ACT_BLOCK_LN32 + rf_gemm). */
+int rf_outer_product_ln_linear(const void* xt, const void* yt, const void* wprime, const float* s, const float* c, float* out,
+                               int B, int L, int N, int P, int Dout, float eps, const float* ln2_gamma, const float* ln2_beta,
+                               float ln2_eps, void* y, int64_t y_ld, void* stream);
+/* Optional tail (PairUpdateWithMsa.ln_coevol_feat, rf.py:443,486): with y != NULL the kernel applies a second LayerNorm
+ * (ln2_gamma / ln2_beta [Dout], ln2_eps) over the Dout outputs of every pair and writes bf16 y[(b,i,j) * y_ld + o] INSTEAD of
+ * `out` (which may then be NULL): the fp32 result and the separate LayerNorm pass over it disappear as well. */
+
 /* PositionWiseWeightFactor core (rf.py:205-217): w[b,n,h,l] = softmax_n( scale * sum_{c<dlen} q0[b,l,h,c]*k[b,n,l,h,c] ).
  * q0: [B,L,H*dlen] (dtype q0_dtype, ld q0_ld); k: T rows [B,N,L,*] of ld k_ld, head h at column k_col0 + h*k_hstride.
  *   - direct form:    q0 = to_q(row 0), k = to_k(x), dlen = k_hstride = d_head;

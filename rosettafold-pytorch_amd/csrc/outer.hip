@@ -1,0 +1,370 @@
+// Fused OuterProductMean (rf.py:412-427) for gfx950 (MI355X): outer product over the MSA depth -> LayerNorm(1024) ->
+// Linear(1024 -> d_pair) in ONE kernel.  Only the [B, L, L, d_pair] result leaves the chip: the 1024-wide feature tensor
+// (537 MB in bf16 at config 2, written and re-read by the round-1 path) never exists.
+//
+//   co[b,i,j,(u,v)] = sum_n x[b,n,i,u] y[b,n,j,v]                       (stage 1, MFMA, K = N)
+//   out[b,i,j,o]    = sum_k LN(co[b,i,j,:])[k] W[o,k] + bias[o]         (stage 2, MFMA, K = 1024)
+//
+// The LayerNorm is folded algebraically so that stage 2 consumes the RAW outer-product block while its statistics are
+// still being accumulated:   out = rstd * ( sum_k co_k W'[o,k]  -  mu * s_o ) + c_o,   W' = W * gamma (bf16),
+// s_o = sum_k W'[o,k],  c_o = sum_k W[o,k] beta_k + bias_o;  mu / rstd come from fp32 sums of the stage-1 accumulators.
+//
+// One 9-wave workgroup owns a tile of TI x TJ = 16 x 8 residue pairs and walks the 1024 features in 16 chunks of
+// (8 u) x (8 v) = 64 features:
+//   stage 1 (waves 0-7): D[(j,v), (i,u)] for the chunk -- 64 x 128 outputs, 16 MFMAs per wave; the lane that holds four
+//            consecutive v of one (pair, u) writes them as 8 bytes into the chunk image A2[pair][64] (LDS, swizzled) and
+//            adds them to the pair's running sum / sum of squares (registers);
+//   stage 2 (all waves): out[pair, 32 w .. 32 w + 31] += A2[pair, :] . W'[o, chunk]: 8 x 2 MFMA tiles x 2 K steps per wave,
+//            W' fragments straight from L2 into registers (every W' element is read once per tile, by one wave).
+// x / y chunks arrive by DMA (global_load_lds) one chunk ahead; two barriers per chunk.
+#include "common.h"
+
+static __device__ __attribute__((aligned(16))) unsigned int g_outer_zero16[4];
+
+struct OuterP {
+  const bf16_t* xt;   // [B, L, 32, N]   x_t[b,i,u,n]  (MSA depth contiguous)
+  const bf16_t* yt;   // [B, L, 32, N]
+  const bf16_t* wp;   // [Dout, 1024]    W * gamma
+  const float* s;     // [Dout]          row sums of wp
+  const float* c;     // [Dout]          W beta + bias
+  float* out;         // [B, L, L, Dout] fp32
+  int B, L, Dout;
+  float eps;
+  // optional second LayerNorm over the Dout outputs of every pair (PairUpdateWithMsa.ln_coevol_feat, rf.py:443,486): when
+  // y != NULL the kernel writes y[pair, 0:Dout] = LN2(out[pair, :]) in bf16 (row stride y_ld elements) INSTEAD of `out`
+  const float* g2;
+  const float* b2;
+  float eps2;
+  bf16_t* y;
+  int64_t y_ld;
+  int ntiles;
+  int dbg;  // timing experiments only (RF_OUTER_DBG; results are wrong when set): 1 skip stage 1, 2 skip stage 2, 4 skip the W'
+            // fragment loads after a tile's first chunk, 8 skip the chunk DMAs after a tile's first, 16 skip the output stores
+};
+
+__device__ __forceinline__ void outer_glds16(const void* src, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ unsigned outer_pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+// workgroup barrier that publishes this wave's LDS writes but leaves its DMAs in flight (a __syncthreads() would drain them)
+__device__ __forceinline__ void outer_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+// NKS = N / 32 (stage-1 K steps): 4 (N = 128) or 2 (N = 64)
+template <int NKS, bool LN2>
+__global__ __launch_bounds__(576) void outer_fused_kernel(const OuterP p) {
+  constexpr int TI = 16, TJ = 8, PT = TI * TJ;   // pairs per tile
+  constexpr int NB = NKS * 64;                   // bytes per operand row (N bf16)
+  constexpr int SPR = NKS * 4;                   // 16-byte slots per operand row
+  constexpr int XCH = TI * 8 * NB;               // x chunk: (i, u in group) rows
+  constexpr int YCH = TJ * 8 * NB;               // y chunk: (j, v in group) rows
+  constexpr int A2B = PT * 128;                  // chunk image: [pair][64 features] bf16
+  constexpr int X_OFF = 0, Y_OFF = 2 * XCH, A2_OFF = Y_OFF + 2 * YCH, ST_OFF = A2_OFF + 2 * A2B;
+  constexpr int RPI = 1024 / NB;                 // rows per DMA instruction
+  constexpr int XI = XCH / 1024, YI = YCH / 1024;
+  constexpr int PDX = (XI + 8) / 9, PDY = (YI + 8) / 9;  // DMA instructions per wave (uniform)
+  constexpr int DUMP_OFF = ST_OFF + PT * 8;              // 1 KB target of the padding DMAs
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int N = NKS * 32;
+
+  // operand-row swizzle (source side of the DMA and fragment reads): N = 128 -> rows are whole 256-byte bank rows,
+  // slot ^ (row & 15); N = 64 -> two rows per bank row, slot ^ ((row >> 1) & 7)
+  auto swz = [](int row) { return NKS == 4 ? (row & 15) : ((row >> 1) & 7); };
+
+  // stage-2 constants of this wave: columns o = 32 wave + 16 c + 4 fq .. +3
+  const int o_w = wave * 32;
+  const bf16_t* const wrow = p.wp + (int64_t)(o_w + fr) * 1024 + fq * 32;  // + cc * 16 rows + (8 ug + 4 s2) * 32 + 8 vg
+
+  // stage-1 geometry of this wave (waves 0-7): y row tile art (rows = (j, v)), x column tiles bct0 .. bct0 + 3 (cols = (i, u))
+  const int art = wave & 3, bct0 = (wave >> 2) * 4;
+  const int jl = 2 * art + (fq >> 1);            // j of this lane's four outputs
+  // column tile t of this wave: i_l = 2 (bct0 + t) + (fr >> 3): pair = pair0 + 16 t, and ((pair >> 1) & 7) does not depend on t
+  const int pair0 = (2 * bct0 + (fr >> 3)) * TJ + jl;
+  const int a2w0 = pair0 * 128 + (((fr & 7) ^ ((pair0 >> 1) & 7)) << 4) + (fq & 1) * 8;  // slot = u, swizzled like the reads
+  const int y_row = 16 * art + fr;               // A operand rows of the y chunk
+  const int y_rd = Y_OFF + y_row * NB;
+  const int x_rd0 = X_OFF + (16 * bct0 + fr) * NB;  // + t * 16 rows
+  // (operand rows r with r & 15 == fr; for N = 64 the swizzle needs (r >> 1) & 7 = (fr >> 1) & 7 -- tiles start at multiples of 16)
+  const int fsw = NKS == 4 ? fr : ((fr >> 1) & 7);
+  // stage-2 A2 reads: pair = 16 rt + fr, slot 4 s2 + fq
+  int a2r[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) a2r[s2] = fr * 128 + (((4 * s2 + fq) ^ ((fr >> 1) & 7)) << 4);  // (+ rt * 2048: (16 rt + fr) >> 1 & 7 == (fr >> 1) & 7)
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int jt = tile % (p.L / TJ), t2 = tile / (p.L / TJ);
+    const int it = t2 % (p.L / TI), b = t2 / (p.L / TI);
+    const int i0 = it * TI, j0 = jt * TJ;
+    const bf16_t* xb = p.xt + ((int64_t)b * p.L + i0) * 32 * N;
+    const bf16_t* yb = p.yt + ((int64_t)b * p.L + j0) * 32 * N;
+
+    // (every wave issues exactly PDX / PDY DMA instructions per call -- padded with dummies -- so the waits can be counted)
+    auto dma_x = [&](int ug) {  // rows (i_l, u_l): i_l = row >> 3, u = 8 ug + (row & 7)
+      char* dst = smem + X_OFF + (ug & 1) * XCH;
+#pragma unroll
+      for (int t = 0; t < PDX; ++t) {
+        const int q = wave + 9 * t;
+        const int row = q * RPI + lane / SPR, sl = lane % SPR;
+        const bf16_t* src = xb + ((int64_t)(row >> 3) * 32 + ug * 8 + (row & 7)) * N + ((sl ^ (swz(row) & (SPR - 1))) << 3);
+        if (q < XI)
+          outer_glds16(src, dst + q * 1024);
+        else
+          outer_glds16(g_outer_zero16, smem + DUMP_OFF);
+      }
+    };
+    auto dma_y = [&](int c) {   // rows (j_l, v_l): j_l = row >> 3, v = 8 vg + (row & 7)
+      char* dst = smem + Y_OFF + (c & 1) * YCH;
+      const int vg = c & 3;
+#pragma unroll
+      for (int t = 0; t < PDY; ++t) {
+        const int q = wave + 9 * t;
+        const int row = q * RPI + lane / SPR, sl = lane % SPR;
+        const bf16_t* src = yb + ((int64_t)(row >> 3) * 32 + vg * 8 + (row & 7)) * N + ((sl ^ (swz(row) & (SPR - 1))) << 3);
+        if (q < YI)
+          outer_glds16(src, dst + q * 1024);
+        else
+          outer_glds16(g_outer_zero16, smem + DUMP_OFF);
+      }
+    };
+    dma_x(0);
+    dma_y(0);
+
+    f32x4 acc[8][2];
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) acc[rt][0] = acc[rt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+
+    // W' fragments (L2 -> registers) run one chunk ahead WITHOUT a second register set: the fragments of K step s2 of chunk
+    // c + 1 are loaded into the registers of step s2 of chunk c as soon as that step's MFMAs have been issued.
+    bf16x8 wf0[2], wf1[2];
+    auto wload = [&](int c, int s2, int cc) {
+      return *(const bf16x8*)(wrow + cc * 16 * 1024 + (8 * (c >> 2) + 4 * s2) * 32 + 8 * (c & 3));
+    };
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      wf0[cc] = wload(0, 0, cc);
+      wf1[cc] = wload(0, 1, cc);
+    }
+
+    // stage 1 of chunk c: D[(j,v)][(i,u)] over the MSA depth -> chunk image A2[c & 1], running statistics
+    auto stage1 = [&](int c) {
+      if (wave >= 8 || (p.dbg & 1)) return;
+      const char* xs = smem + ((c >> 2) & 1) * XCH;
+      const char* ys = smem + (c & 1) * YCH;
+      f32x4 d[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) d[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        const int sl = ((4 * s + fq) ^ fsw) << 4;
+        const bf16x8 yf = *(const bf16x8*)(ys + y_rd + sl);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bf16x8 xf = *(const bf16x8*)(xs + x_rd0 + t * 16 * NB + sl);
+          d[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf, xf, d[t], 0, 0, 0);  // lane: (j,v) = 4 fq + r, (i,u) = fr
+        }
+      }
+      // (LDS store through inline asm: hipcc puts s_waitcnt vmcnt(0) in front of a visible ds_write while LDS-DMAs are in
+      // flight -- it cannot tell that the DMA targets and the chunk image are disjoint.  The dynamic LDS segment starts at
+      // LDS address 0: the kernel has no static __shared__.)
+      const unsigned a2a = (unsigned)(A2_OFF + (c & 1) * A2B + a2w0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        ssum[t] += (d[t][0] + d[t][1]) + (d[t][2] + d[t][3]);
+        ssq[t] += (d[t][0] * d[t][0] + d[t][1] * d[t][1]) + (d[t][2] * d[t][2] + d[t][3] * d[t][3]);
+        uint2 w;
+        w.x = outer_pack2(d[t][0], d[t][1]);
+        w.y = outer_pack2(d[t][2], d[t][3]);
+        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a2a), "v"(w), "i"(t * 2048) : "memory");
+      }
+    };
+    // one K step (32 features) of stage 2 of chunk c: out[pair, o] += A2[pair, chunk] . W'[o, chunk]
+    // W' tile as MFMA-A, chunk image as MFMA-B: lane holds out[pair = 16 rt + fr][o = 32 w + 16 cc + 4 fq .. +3]
+    auto stage2 = [&](int c, int s2, const bf16x8 (&wf)[2]) {
+      if (p.dbg & 2) return;
+      const char* a2 = smem + A2_OFF + (c & 1) * A2B;
+#pragma unroll
+      for (int r0 = 0; r0 < 8; r0 += 4) {  // four image fragments in flight per batch of eight MFMAs
+        bf16x8 af[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) af[k] = *(const bf16x8*)(a2 + (r0 + k) * 2048 + a2r[s2]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+            acc[r0 + k][cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cc], af[k], acc[r0 + k][cc], 0, 0, 0);
+      }
+    };
+
+    // prologue: chunk 0's operands landed -> stage 1 of chunk 0 (its image is consumed in iteration 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    outer_lds_barrier();
+    if (!(p.dbg & 8)) dma_y(1);
+    stage1(0);
+    // iteration c: stage 2 of chunk c runs beside stage 1 of chunk c + 1 (independent work in one instruction stream); ONE
+    // barrier per chunk.  Everything issued during iteration c - 1 (the DMAs of chunk c + 1, the W' fragments of chunk c) is
+    // waited for at the top: there is nothing younger, so the plain vmcnt(0) is exact.
+    for (int c = 0; c < 16; ++c) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {  // (pins the compiler's own wait for the W' loads here, ahead of the DMA issue below)
+        asm volatile("" : "+v"(wf0[cc]));
+        asm volatile("" : "+v"(wf1[cc]));
+      }
+      outer_lds_barrier();  // image of chunk c complete; operands of chunk c + 1 visible; y[c & 1] and x[...] of chunk c free
+      const bool more = c + 2 < 16 && !(p.dbg & 8);
+      if (more) dma_y(c + 2);                              // into y[c & 1] (read by stage 1 of chunk c, done)
+      if (more && ((c + 2) & 3) == 0) dma_x((c + 2) >> 2);  // group of chunks c + 2 .. c + 5, into the buffer of group (c >> 2) - 1
+      stage2(c, 0, wf0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < 16 && !(p.dbg & 4)) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) wf0[cc] = wload(c + 1, 0, cc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      stage2(c, 1, wf1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < 16 && !(p.dbg & 4)) {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) wf1[cc] = wload(c + 1, 1, cc);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < 16) stage1(c + 1);
+    }
+    // ---------------- statistics: reduce over the 16 lanes that share a pair, publish, normalise ----------------
+    float* stats = (float*)(smem + ST_OFF);
+    if (wave < 8) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float a = ssum[t], q = ssq[t];
+#pragma unroll
+        for (int o = 1; o <= 4; o <<= 1) {
+          a += __shfl_xor(a, o, 64);
+          q += __shfl_xor(q, o, 64);
+        }
+        a += __shfl_xor(a, 16, 64);
+        q += __shfl_xor(q, 16, 64);
+        if ((fr & 7) == 0 && (fq & 1) == 0) {
+          stats[2 * (pair0 + 16 * t)] = a;
+          stats[2 * (pair0 + 16 * t) + 1] = q;
+        }
+      }
+    }
+    outer_lds_barrier();
+    f32x4 s4[2], c4[2];  // (loaded per tile: resident copies cost 16 registers of the 168 a 9-wave workgroup may use)
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      s4[cc] = *(const f32x4*)(p.s + o_w + cc * 16 + 4 * fq);
+      c4[cc] = *(const f32x4*)(p.c + o_w + cc * 16 + 4 * fq);
+    }
+    float* part = (float*)(smem + A2_OFF);  // LN2 partial sums [9 waves][128 pairs][2] (the chunk images are dead here)
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+      const int pr = 16 * rt + fr;
+      const float2 sq = *(const float2*)(stats + 2 * pr);
+      const float mu = sq.x * (1.0f / 1024.0f);
+      const float var = fmaxf(sq.y * (1.0f / 1024.0f) - mu * mu, 0.f);
+      const float rstd = rsqrtf(var + p.eps);
+      if constexpr (LN2) {
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          acc[rt][cc] = (acc[rt][cc] - mu * s4[cc]) * rstd + c4[cc];  // Linear(LayerNorm_1024(co)), kept in the accumulators
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a += acc[rt][cc][e];
+            q = fmaf(acc[rt][cc][e], acc[rt][cc][e], q);
+          }
+        }
+        a += __shfl_xor(a, 16, 64); q += __shfl_xor(q, 16, 64);
+        a += __shfl_xor(a, 32, 64); q += __shfl_xor(q, 32, 64);
+        if (fq == 0) *(float2*)(part + (wave * PT + pr) * 2) = make_float2(a, q);
+      } else {
+        float* orow = p.out + (((int64_t)b * p.L + i0 + (pr >> 3)) * p.L + j0 + (pr & 7)) * p.Dout + o_w + 4 * fq;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const f32x4 v = (acc[rt][cc] - mu * s4[cc]) * rstd + c4[cc];
+          if (!(p.dbg & 16)) *(f32x4*)(orow + cc * 16) = v;
+        }
+      }
+    }
+    if constexpr (LN2) {
+      // second LayerNorm (over the 288 outputs of a pair = the 9 waves' 32-column slices): per-wave partial sums meet in LDS
+      outer_lds_barrier();
+      if (tid < PT) {
+        float a = 0.f, q = 0.f;
+#pragma unroll
+        for (int w9 = 0; w9 < 9; ++w9) {
+          const float2 t2 = *(const float2*)(part + (w9 * PT + tid) * 2);
+          a += t2.x;
+          q += t2.y;
+        }
+        const float m2 = a / (float)p.Dout;
+        const float v2 = fmaxf(q / (float)p.Dout - m2 * m2, 0.f);
+        *(float2*)(stats + 2 * tid) = make_float2(m2, rsqrtf(v2 + p.eps2));
+      }
+      outer_lds_barrier();
+      f32x4 g4[2], e4[2];
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        g4[cc] = *(const f32x4*)(p.g2 + o_w + cc * 16 + 4 * fq);
+        e4[cc] = *(const f32x4*)(p.b2 + o_w + cc * 16 + 4 * fq);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 8; ++rt) {
+        const int pr = 16 * rt + fr;
+        const float2 ms = *(const float2*)(stats + 2 * pr);
+        bf16_t* yrow = p.y + (((int64_t)b * p.L + i0 + (pr >> 3)) * p.L + j0 + (pr & 7)) * p.y_ld + o_w + 4 * fq;
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const f32x4 v = (acc[rt][cc] - ms.x) * ms.y * g4[cc] + e4[cc];
+          uint2 w;
+          w.x = outer_pack2(v[0], v[1]);
+          w.y = outer_pack2(v[2], v[3]);
+          if (!(p.dbg & 16)) *(uint2*)(yrow + cc * 16) = w;
+        }
+      }
+    }
+    outer_lds_barrier();  // stats / chunk images are free for the next tile
+  }
+}
+
+template <int NKS, bool LN2>
+static int launch_outer(OuterP& p, hipStream_t s) {
+  constexpr int NB = NKS * 64;
+  constexpr int LDS = 2 * (16 * 8 * NB) + 2 * (8 * 8 * NB) + 2 * (128 * 128) + 128 * 8 + 1024;
+  const int ncu = rf_num_cus() > 0 ? rf_num_cus() : 256;
+  p.ntiles = p.B * (p.L / 16) * (p.L / 8);
+  const int grid = p.ntiles < ncu ? p.ntiles : ncu;
+  if (const int e = rf_enable_big_lds<outer_fused_kernel<NKS, LN2>>()) return e;
+  hipLaunchKernelGGL((outer_fused_kernel<NKS, LN2>), dim3((unsigned)grid), dim3(576), LDS, s, p);
+  return rf_launch_status();
+}
+
+extern "C" int rf_outer_product_ln_linear(const void* xt, const void* yt, const void* wprime, const float* s, const float* c,
+                                          float* out, int B, int L, int N, int P, int Dout, float eps, const float* ln2_gamma,
+                                          const float* ln2_beta, float ln2_eps, void* y, int64_t y_ld, void* stream) {
+  if (!xt || !yt || !wprime || !s || !c || B <= 0) return RF_EINVAL;
+  if (!y && !out) return RF_EINVAL;
+  if (y && (!ln2_gamma || !ln2_beta || y_ld < Dout || y_ld % 4 || ((uintptr_t)y % 8) || ((uintptr_t)ln2_gamma % 16) || ((uintptr_t)ln2_beta % 16)))
+    return RF_EINVAL;
+  if (P != 32 || Dout != 288 || (N != 128 && N != 64) || L % 16 != 0 || L < 16) return RF_EINVAL;  // (other shapes: rf_gemm + rf_layernorm)
+  if (((uintptr_t)xt % 16) || ((uintptr_t)yt % 16) || ((uintptr_t)wprime % 16) || ((uintptr_t)s % 16) || ((uintptr_t)c % 16) ||
+      ((uintptr_t)out % 16))
+    return RF_EALIGN;
+  OuterP p;
+  p.xt = (const bf16_t*)xt; p.yt = (const bf16_t*)yt; p.wp = (const bf16_t*)wprime; p.s = s; p.c = c; p.out = out;
+  p.B = B; p.L = L; p.Dout = Dout; p.eps = eps;
+  static const int dbg = getenv("RF_OUTER_DBG") ? atoi(getenv("RF_OUTER_DBG")) : 0;
+  p.dbg = dbg;
+  p.g2 = ln2_gamma; p.b2 = ln2_beta; p.eps2 = ln2_eps; p.y = (bf16_t*)y; p.y_ld = y_ld;
+  hipStream_t st = (hipStream_t)stream;
+  if (y) return N == 128 ? launch_outer<4, true>(p, st) : launch_outer<2, true>(p, st);
+  return N == 128 ? launch_outer<4, false>(p, st) : launch_outer<2, false>(p, st);
+}

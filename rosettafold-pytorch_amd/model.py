@@ -36,6 +36,7 @@ class _Runtime:
     fused_favor = True  # use the fused FAVOR+ kernel when the shape allows (bf16, dim_head 64, seq 128/256)
     fused_outer_ln = not bool(int(__import__("os").environ.get("RF_NO_FUSED_OUTER_LN", "0")))  # LayerNorm(1024) in the outer-product GEMM epilogue
     fused_tied = not bool(int(__import__("os").environ.get("RF_NO_FUSED_TIED", "0")))  # tied-attention logits + softmax in one launch
+    fused_outer = not bool(int(__import__("os").environ.get("RF_NO_FUSED_OUTER", "0")))  # outer product -> LN -> Linear in one kernel
     tied_v2 = not bool(int(__import__("os").environ.get("RF_TIED_V1", "0")))  # head-major q|k|v + collapsed weights + A.V kernel
     head_major_qkv = bool(int(__import__("os").environ.get("RF_HEAD_MAJOR_QKV", "0")))
     # Producer -> consumer chains whose intermediate (q|k|v, feed-forward hidden) is larger than this many bytes are run
@@ -755,12 +756,32 @@ class OuterProductMean(RFModule):
         super().__init__()
         self.to_out = nn.Sequential(LayerNorm(in_features ** 2), Linear(in_features ** 2, out_features))
 
+    def fused_ok(self, P, N, Lr):
+        return (RT.fused_outer and T() == torch.bfloat16 and P == 32 and N in (64, 128) and Lr % 16 == 0
+                and self.to_out[1].weight.shape[0] == 288)
+
+    def run_into(self, x_t, y_t, ln2, feat, feat_ld):
+        """Fused form with the consumer's LayerNorm (PairUpdateWithMsa.ln_coevol_feat) in the epilogue: writes bf16
+        feat[..., 0:288] directly; neither the 1024-wide tensor nor the fp32 result exists."""
+        lnm, lin = self.to_out[0], self.to_out[1]
+        wp, s_, c_ = self.cached("outer_fold", lambda: ops.outer_fold(lin.weight.detach(), lnm.weight.detach(),
+                                                                        lnm.bias.detach(), lin.bias.detach()))
+        return ops.outer_fused(x_t, y_t, wp, s_, c_, None, lnm.eps, ln2=(_f(ln2.weight), _f(ln2.bias), ln2.eps, feat, feat_ld))
+
     def run(self, x_t, y_t, N):
         """x_t, y_t: T [B, L, P, N] (MSA depth contiguous).  -> fp32 [B,L,L,out]"""
         B, Lr, P, _ = x_t.shape
         PP = P * P
-        co = torch.empty(B, Lr, Lr, PP, device=x_t.device, dtype=T())
         lnm = self.to_out[0]
+        lin = self.to_out[1]
+        if self.fused_ok(P, N, Lr):
+            # one kernel: outer product over the MSA depth -> LayerNorm(1024) (folded algebraically) -> Linear; the 1024-wide
+            # tensor never leaves the chip (csrc/outer.hip)
+            wp, s_, c_ = self.cached("outer_fold", lambda: ops.outer_fold(lin.weight.detach(), lnm.weight.detach(),
+                                                                            lnm.bias.detach(), lin.bias.detach()))
+            out = torch.empty(B, Lr, Lr, lin.weight.shape[0], device=x_t.device, dtype=F32)
+            return ops.outer_fused(x_t, y_t, wp, s_, c_, out, lnm.eps)
+        co = torch.empty(B, Lr, Lr, PP, device=x_t.device, dtype=T())
         if T() == torch.bfloat16 and P == 32 and (Lr * P) % 256 == 0 and N >= 64 and RT.fused_outer_ln:
             # LayerNorm(1024) of every pair's outer-product block inside the GEMM epilogue (fp32 statistics on the
             # accumulators): the separate pass over the 0.5 GB feature tensor disappears
@@ -836,7 +857,6 @@ class PairUpdateWithMsa(RFModule):
         yt = mk(B, Lr, P, Np, device=dev, dtype=T())
         for src, dst in ((mp, xt), (mpw, yt)):
             ops.copy4d(src, (N * Lr * P, P, 1, Lr * P), dst, (Lr * P * Np, P * Np, Np, 1), (B, Lr, P, N))
-        coevol = self.outer_product_mean.run(xt, yt, Np)  # fp32 [B,L,L,Dp]
         # feature tensor (K padded to a multiple of 8)
         Kf = pad8(self.d_feat)
         feat = torch.empty(B, Lr, Lr, Kf, device=dev, dtype=T())  # every feature column is written below; only the K padding
@@ -844,7 +864,11 @@ class PairUpdateWithMsa(RFModule):
             zpad = ops.zeros(B * Lr * Lr, Kf - self.d_feat, device=dev, dtype=T())
             ops.copy4d(zpad, (0, 0, Kf - self.d_feat, 1), feat, (0, 0, Kf, 1), (1, 1, B * Lr * Lr, Kf - self.d_feat),
                        y_off=self.d_feat)
-        ln(self.ln_coevol_feat, coevol, out=feat, out_ld=Kf, out_off=0)
+        if self.outer_product_mean.fused_ok(P, Np, Lr) and Dp == 288:
+            self.outer_product_mean.run_into(xt, yt, self.ln_coevol_feat, feat, Kf)  # outer -> LN -> Linear -> LN -> feat[..., :Dp]
+        else:
+            coevol = self.outer_product_mean.run(xt, yt, Np)  # fp32 [B,L,L,Dp]
+            ln(self.ln_coevol_feat, coevol, out=feat, out_ld=Kf, out_off=0)
         ops.tile_1d_feats(msa1d, feat, Kf, Dp, B, Lr, 2 * P)
         ln(self.ln_pair, pair, out=feat, out_ld=Kf, out_off=Dp + 4 * P)
         H = att.shape[-1]

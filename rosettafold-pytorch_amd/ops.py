@@ -200,6 +200,40 @@ def tied_row_attention(q, k, v):
     return out, sym
 
 
+def outer_fused(xt, yt, wprime, s, c, out, eps, ln2=None):
+    """Fused OuterProductMean core (csrc/outer.hip): xt, yt bf16 [B, L, 32, N]; wprime bf16 [Dout, 1024]; out fp32 [B,L,L,Dout].
+    ln2 = (gamma, beta, eps, y, y_ld): also apply LayerNorm over Dout and write bf16 y[(b,i,j) * y_ld + o] instead of `out`."""
+    B, L_, P, N = xt.shape
+    _need_cuda(xt, yt, wprime, s, c, out)
+    g2 = b2 = y = None
+    eps2, y_ld = 0.0, 0
+    if ln2 is not None:
+        g2, b2, eps2, y, y_ld = ln2
+        _need_cuda(g2, b2, y)
+    check(lib.rf_outer_product_ln_linear(ptr(xt), ptr(yt), ptr(wprime), ptr(s), ptr(c), ptr(out), B, L_, N, P, wprime.shape[0],
+                                         float(eps), ptr(g2), ptr(b2), float(eps2), ptr(y), int(y_ld), stream()),
+          "rf_outer_product_ln_linear")
+    return y if ln2 is not None else out
+
+
+def outer_fold(w, gamma, beta, bias):
+    """(W * gamma in bf16, its fp32 row sums, W beta + bias): the LayerNorm(1024) affine folded into Linear(1024 -> Dout)."""
+    wp = (w.float() * gamma.float()[None, :]).to(BF16).contiguous()
+    return wp, wp.float().sum(1).contiguous(), (w.float() @ beta.float() + bias.float()).contiguous()
+
+
+def outer_product_ln_linear(x, y, gamma, beta, w, b, eps):
+    """Functional form (dispatcher op): x, y bf16 [B, N, L, 32] -> fp32 [B, L, L, Dout]."""
+    B, N, L_, P = x.shape
+    xt = torch.empty(B, L_, P, N, device=x.device, dtype=BF16)
+    yt = torch.empty(B, L_, P, N, device=x.device, dtype=BF16)
+    for src, dst in ((x, xt), (y, yt)):
+        copy4d(src.contiguous(), (N * L_ * P, P, 1, L_ * P), dst, (L_ * P * N, P * N, N, 1), (B, L_, P, N))
+    wp, s, c = outer_fold(w, gamma, beta, b)
+    out = torch.empty(B, L_, L_, w.shape[0], device=x.device, dtype=F32)
+    return outer_fused(xt, yt, wp, s, c, out, eps)
+
+
 def poswise_collapsed(xn, u, scale):
     """w[b,h,n,l] = softmax_n(scale * xn[b,n,l,:] . u[b,l,h,:]); xn bf16 [B,N,L,D], u bf16 [B,L,H,D] -> fp32 [B,H,N,L]."""
     B, N, L_, D = xn.shape

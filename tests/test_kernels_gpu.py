@@ -387,6 +387,41 @@ def test_gemm_persistent_split_c(N, BNexp):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("B,N,Lr", [(1, 128, 16), (2, 128, 48), (1, 64, 32)])
+def test_outer_product_fused(B, N, Lr):
+    """Fused OuterProductMean (csrc/outer.hip): outer product over the MSA depth -> LayerNorm(1024) -> Linear(1024 -> 288) in
+    one kernel, against einsum + layer_norm + linear in fp32 on the same bf16 inputs (rf.py:412-427)."""
+    P, Dout = 32, 288
+    x, y = randn(B, N, Lr, P).bfloat16(), (randn(B, N, Lr, P, seed=1) * 0.3).bfloat16()
+    g_, b_ = 1.0 + 0.2 * randn(P * P, seed=2), 0.1 * randn(P * P, seed=3)
+    w, bias = randn(Dout, P * P, seed=4) * 0.05, randn(Dout, seed=5)
+    co = torch.einsum("bniu,bnjv->bijuv", x.float(), y.float()).reshape(B, Lr, Lr, P * P)
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(co, (P * P,), g_, b_, 1e-5), w, bias)
+    out = ops.outer_product_ln_linear(x, y, g_, b_, w, bias, 1e-5)
+    assert rel_err(out, ref) < 1.5e-2
+    # exact structure check: with gamma = 1, beta = 0 and a W that picks single features the kernel must reproduce LN(co)[k]
+    sel = torch.zeros(Dout, P * P, device=DEV)
+    ks = torch.randperm(P * P, generator=torch.Generator().manual_seed(7))[:Dout].to(DEV)
+    sel[torch.arange(Dout, device=DEV), ks] = 1.0
+    out = ops.outer_product_ln_linear(x, y, torch.ones(P * P, device=DEV), torch.zeros(P * P, device=DEV), sel,
+                                      torch.zeros(Dout, device=DEV), 1e-5)
+    ref = torch.nn.functional.layer_norm(co, (P * P,))[..., ks]
+    assert rel_err(out, ref) < 1.5e-2  # (bf16 rounding of the raw blocks; an index mix-up would be O(1))
+    # with the consumer's LayerNorm(288) in the epilogue (bf16 rows written into a wider feature tensor)
+    g2, b2 = 1.0 + 0.2 * randn(Dout, seed=8), 0.1 * randn(Dout, seed=9)
+    xt = x.permute(0, 2, 3, 1).contiguous()
+    yt = y.permute(0, 2, 3, 1).contiguous()
+    wp, s_, c_ = ops.outer_fold(w, g_, b_, bias)
+    feat = torch.full((B, Lr, Lr, 304), 3.0, device=DEV, dtype=torch.bfloat16)
+    ops.outer_fused(xt, yt, wp, s_, c_, None, 1e-5, ln2=(g2, b2, 1e-5, feat, 304))
+    ref1 = torch.nn.functional.linear(torch.nn.functional.layer_norm(co, (P * P,), g_, b_, 1e-5), w, bias)
+    assert rel_err(feat[..., :Dout], torch.nn.functional.layer_norm(ref1, (Dout,), g2, b2, 1e-5)) < 2e-2
+    assert (feat[..., Dout:] == 3.0).all()
+    import rosettafold_pytorch_amd.custom_ops  # noqa: F401
+    out2 = torch.ops.rfmi.outer_product_ln_linear(x, y, g_, b_, w, bias, 1e-5)
+    assert rel_err(out2, torch.nn.functional.linear(torch.nn.functional.layer_norm(co, (P * P,), g_, b_, 1e-5), w, bias)) < 1.5e-2
+
+
 def test_gemm_block_layernorm_epilogue():
     """Outer-product GEMM with LayerNorm(1024) of every 32x32 output block in the epilogue (OuterProductMean, rf.py:416,
     424-426) against einsum + layer_norm; operands / output laid out exactly as the model's call."""
