@@ -435,6 +435,34 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
   }
 }
 
+// global -> LDS DMA issued from inline assembly: hipcc's wait-count pass then knows nothing of it.  (With the builtin it
+// tracks "LDS written by DMA" and puts s_waitcnt vmcnt(0) before every later ds_read_tr / ds_write / merged ds_read2 it
+// cannot disambiguate -- those waits also drain the younger Q loads and output stores.)  All waits for these DMAs are the
+// counted s_waitcnt vmcnt(N) written out in the kernel.  lds_addr: wave-uniform LDS byte address of the wave's 1 KB slot.
+#pragma clang diagnostic ignored "-Winline-asm"  // m0 on the clobber list is intended: no other M0 user in that kernel
+__device__ __forceinline__ void fv_glds_asm(const void* src, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src) : "memory", "m0");
+}
+
+// workgroup barrier that publishes this wave's LDS writes and leaves its global loads / stores / DMAs in flight
+// (__syncthreads() carries a release fence that hipcc lowers to s_waitcnt vmcnt(0): it would drain the K/V prefetch, the
+// Q loads of the running item and the output stores of the previous one at every barrier)
+__device__ __forceinline__ void fv_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// phase timing of the 8-wave kernel (RF_FAVOR_DBG bit 8; tools/favor_bench.py reads it through rf_favor_phase_cycles):
+// s_memtime cycles of wave 0 of every workgroup, summed: [0] wait for K/V, [1] phase A, [2] publish + barrier, [3] prefetch issue + combine, [4] phase B, [5] stores, [6] items
+__device__ unsigned long long g_fv_cycles[8];
+#define FV_STAMP(slot)                                                   \
+  if (prof) {                                                            \
+    const unsigned long long now = __builtin_readcyclecounter();         \
+    acc_cyc[slot] += now - t_last;                                       \
+    t_last = now;                                                        \
+  }
+
 // ------------------------------------------------------------------------------------------------------------------
 // 8-wave variant (2 waves per SIMD: a lone wave issues one VALU op per 4 cycles, two co-resident waves one per 2, and
 // the feature maps are VALU-bound).  Phase A: wave = (feature group g = 5,4,4,4 tiles) x (sequence half hs); the two
@@ -457,7 +485,9 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
-  const int g = wave & 3, hs = wave >> 2;
+  // (feature group, sequence half); waves w and w + 4 share a SIMD: rotating the group of the second half keeps the two
+  // 5-tile waves (g = 0) on different SIMDs (9 + 9 + 8 + 8 tile units instead of 10 + 8 + 8 + 8)
+  const int hs = wave >> 2, g = (wave + hs) & 3;
   const int fr = lane & 15, fq = lane >> 4;
   const int nm = g == 0 ? 5 : 4;
   const int m0t = g == 0 ? 0 : 5 + 4 * (g - 1);
@@ -466,16 +496,22 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
 #pragma unroll
   for (int k = 0; k < 4; ++k) ones.u[k] = fr == 0 ? 0x3F803F80u : 0u;
 
-  auto load_tile8 = [&](int lds_off, const bf16_t* gp, int64_t stride, int nrows) {
-    const int ninstr = nrows * 8 / 64;
-    for (int it = wave; it < ninstr; it += 8) {
-      const int slot = it * 64 + lane;
-      const int row = slot >> 3;
-      const int clog = (slot & 7) ^ (row & 7);
-      fv_glds(gp + (int64_t)row * stride + clog * 8, smem + lds_off + it * 1024);
+  // [nrows][64] bf16 tile -> swizzled LDS image; a wave's instruction covers 8 rows (row = 8*it + lane/8, rows & 7 == lane/8)
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int dma_row = lane >> 3;
+  const int dma_col = ((lane & 7) ^ dma_row) * 8;
+  auto load_tile8 = [&](int lds_off, const bf16_t* gp, int64_t stride, auto nrows_tag) {
+    constexpr int NI = decltype(nrows_tag)::value * 8 / 64;
+    const bf16_t* g0 = gp + (int64_t)dma_row * stride + dma_col;
+#pragma unroll
+    for (int k = 0; k < (NI + 7) / 8; ++k) {
+      const int it = wave + 8 * k;
+      if (NI % 8 == 0 || it < NI)
+        fv_glds_asm(g0 + (int64_t)(8 * it) * stride, __builtin_amdgcn_readfirstlane(lds_base + lds_off + it * 1024));
     }
   };
-  load_tile8(PC_OFF, p.pc, FV_DH, FV_MPAD);
+  constexpr std::integral_constant<int, LS> LS_TAG{};
+  load_tile8(PC_OFF, p.pc, FV_DH, std::integral_constant<int, FV_MPAD>{});
   for (int i = tid; i < FV_DROWS * FV_CTX_LD / 4; i += 512) ((unsigned*)(smem + CTX_OFF))[i] = 0u;
 
   auto item_base = [&](int item, int64_t& xb, int64_t& ob) {
@@ -485,24 +521,33 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
     xb = (int64_t)b * p.x_b + (int64_t)o * p.x_o + (int64_t)h * p.x_h;
     ob = (int64_t)b * p.o_b + (int64_t)o * p.o_o + h * FV_DH;
   };
+  auto ctx_col = [](int tile, int q4) { return ((tile >> 1) * 32 + 8 * q4 + 4 * (tile & 1)) * 2; };
   const int nch = p.nchunks;
   int item = blockIdx.x;
   if (item < p.nitems) {
     int64_t xb, ob;
     item_base(item, xb, ob);
-    load_tile8(K_OFF, p.qkv + xb + p.k_off, p.x_s, LS);
-    load_tile8(V_OFF, p.qkv + xb + p.v_off, p.x_s, LS);
+    load_tile8(K_OFF, p.qkv + xb + p.k_off, p.x_s, LS_TAG);
+    load_tile8(V_OFF, p.qkv + xb + p.v_off, p.x_s, LS_TAG);
   }
   bool first = true;
+  const bool prof = (p.dbg & 8) && wave == ((p.dbg >> 4) & 7);
+  unsigned long long acc_cyc[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = prof ? __builtin_readcyclecounter() : 0;
   for (; item < p.nitems; item += gridDim.x) {
     int64_t xb, ob;
     item_base(item, xb, ob);
+    if (prof) {
+      t_last = __builtin_readcyclecounter();
+      acc_cyc[6] += 1;
+    }
     if (first || wave >= NWB)  // (waves idle in phase B issued no stores: their youngest operations are the DMAs)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(STB * 4) : "memory");
     first = false;
-    __syncthreads();
+    fv_lds_barrier();
+    FV_STAMP(0)
     bf16x8 qf[STB][2];
     auto load_q = [&](int chunk) {
       if (wave < NWB) {
@@ -560,7 +605,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
       }
       mx = wave_max(mx);
       if (lane == 0) ((float*)(smem + RED_OFF))[wave] = mx;
-      __syncthreads();
+      fv_lds_barrier();
       const float* red = (const float*)(smem + RED_OFF);
       gmax = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
     }
@@ -574,8 +619,8 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
     for (int ck = 0; ck < nch; ++ck) {
       if (ck > 0) {
         __syncthreads();
-        load_tile8(K_OFF, p.qkv + xb + p.k_off + (int64_t)ck * LS * p.x_s, p.x_s, LS);
-        load_tile8(V_OFF, p.qkv + xb + p.v_off + (int64_t)ck * LS * p.x_s, p.x_s, LS);
+        load_tile8(K_OFF, p.qkv + xb + p.k_off + (int64_t)ck * LS * p.x_s, p.x_s, LS_TAG);
+        load_tile8(V_OFF, p.qkv + xb + p.v_off + (int64_t)ck * LS * p.x_s, p.x_s, LS_TAG);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
       }
@@ -649,6 +694,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
         }
       }
     }
+    FV_STAMP(1)
     // combine the two sequence halves through the ctx^T image: half 1 publishes, half 0 adds and republishes
     if (hs == 1) {
 #pragma unroll
@@ -659,42 +705,65 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
             uint2 w;
             w.x = pack2(ctx[j][i][0], ctx[j][i][1]);
             w.y = pack2(ctx[j][i][2], ctx[j][i][3]);
-            *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ((m0t + j) * 16 + 4 * fq) * 2) = w;
+            *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq)) = w;
           }
         }
     }
-    __syncthreads();
-    if (hs == 0) {
-#pragma unroll
-      for (int j = 0; j < 5; ++j)
-        if (j < nm) {
-#pragma unroll
-          for (int i = 0; i < FV_DT; ++i) {
-            uint2* ptr = (uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ((m0t + j) * 16 + 4 * fq) * 2);
-            const uint2 o = *ptr;
-            uint2 w;
-            w.x = pack2(ctx[j][i][0] + bf2f((bf16_t)(o.x & 0xffff)), ctx[j][i][1] + bf2f((bf16_t)(o.x >> 16)));
-            w.y = pack2(ctx[j][i][2] + bf2f((bf16_t)(o.y & 0xffff)), ctx[j][i][3] + bf2f((bf16_t)(o.y >> 16)));
-            *ptr = w;
-          }
-        }
-    }
-    __syncthreads();  // ctx^T complete; K and V tiles are free again
-
+    fv_lds_barrier();  // every wave is through phase A: the K and V tiles are free again
+    FV_STAMP(2)
+    // Pin the Q fragments here (loaded a whole phase ago): hipcc's own wait for them lands at this point, BEFORE the
+    // prefetch DMAs are issued; left to itself it waits at their first use in phase B with vmcnt(0), which also drains
+    // the K/V prefetch it cannot count (in-order counter) and serialises the item pipeline.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < STB; ++t) {
+      asm volatile("" : "+v"(qf[t][0]), "+v"(qf[t][1]));
+    }
     {
       const int nxt = item + gridDim.x;
       if (nxt < p.nitems) {
         int64_t xb2, ob2;
         item_base(nxt, xb2, ob2);
-        load_tile8(K_OFF, p.qkv + xb2 + p.k_off, p.x_s, LS);
-        load_tile8(V_OFF, p.qkv + xb2 + p.v_off, p.x_s, LS);
+        load_tile8(K_OFF, p.qkv + xb2 + p.k_off, p.x_s, LS_TAG);
+        load_tile8(V_OFF, p.qkv + xb2 + p.v_off, p.x_s, LS_TAG);
       }
     }
+    if (hs == 0) {
+      // all partner partials first (independent reads in flight together), then add and republish: a read-modify-write
+      // per tile would be a chain of 25 LDS round trips
+      uint2 o[5][FV_DT];
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        if (j < nm) {
+#pragma unroll
+          for (int i = 0; i < FV_DT; ++i)
+            o[j][i] = *(const uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq));
+        }
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        if (j < nm) {
+#pragma unroll
+          for (int i = 0; i < FV_DT; ++i) {
+            uint2 w;
+            w.x = pack2(ctx[j][i][0] + bf2f((bf16_t)(o[j][i].x & 0xffff)), ctx[j][i][1] + bf2f((bf16_t)(o[j][i].x >> 16)));
+            w.y = pack2(ctx[j][i][2] + bf2f((bf16_t)(o[j][i].y & 0xffff)), ctx[j][i][3] + bf2f((bf16_t)(o[j][i].y >> 16)));
+            *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq)) = w;
+          }
+        }
+    }
+    fv_lds_barrier();  // ctx^T complete
 
+    FV_STAMP(3)
     // ---------------- phase B ----------------
     for (int qc = 0; qc < nch; ++qc) {
-      if (qc > 0) load_q(qc);
+      if (qc > 0) {
+        load_q(qc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < STB; ++t) {
+          asm volatile("" : "+v"(qf[t][0]), "+v"(qf[t][1]));
+        }
+      }
       if (wave < NWB) {
         f32x4 qinit[STB];
 #pragma unroll
@@ -775,13 +844,10 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
               }
             }
           }
-          Frag cf[FV_DT];
+          Frag cf[FV_DT];  // one 16-byte read per fragment: the image keeps a lane's 8 k-slots (2 tiles x 4 rows) adjacent
 #pragma unroll
-          for (int i = 0; i < FV_DT; ++i) {
-            const char* base = smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + (32 * u + 4 * fq) * 2;
-            cf[i].h[0] = *(const uint2*)base;
-            cf[i].h[1] = *(const uint2*)(base + 32);
-          }
+          for (int i = 0; i < FV_DT; ++i)
+            cf[i].v = *(const bf16x8*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + (32 * u + 8 * fq) * 2);
 #pragma unroll
           for (int t = 0; t < STB; ++t) {
             Frag qfr;
@@ -796,6 +862,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
         };
         for (int u = 0; u < ((p.dbg & 2) ? 0 : (FV_MT - 1) / 2); ++u) mblock(u, std::false_type{});
         mblock((FV_MT - 1) / 2, std::true_type{});
+        FV_STAMP(4)
 #pragma unroll
         for (int t = 0; t < STB; ++t) {
           const float dn = __shfl(num[4][t][0], fr, 64);
@@ -812,7 +879,19 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
         }
       }
     }
+    FV_STAMP(5)
   }
+  if (prof && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) atomicAdd(&g_fv_cycles[i], acc_cyc[i]);
+  }
+}
+
+extern "C" int rf_favor_phase_cycles(unsigned long long* out7, int reset) {
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (out7 && hipMemcpyFromSymbol(out7, HIP_SYMBOL(g_fv_cycles), 7 * sizeof(unsigned long long)) != hipSuccess) return 1000 + (int)hipGetLastError();
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_fv_cycles), z, sizeof(z)) != hipSuccess) return 1000 + (int)hipGetLastError();
+  return 0;
 }
 
 template <int LS, bool SM>

@@ -23,3 +23,18 @@ for name, gen, B, L1, L2, D, H, axis in [("pair row", True, 4, 256, 256, 288, 8,
     t = timeit(f)
     fl = B * Lo * H * (4 * 2 * Ls * 64 * 266)
     print(f"{name}: {t*1e3:.0f} us, {fl/t/1e9:.0f} TF/s (algorithmic, 266 features)", flush=True)
+    # head-major q|k|v tiles: [Lo, 3H, B, Ls, 64] (every item's K / V / Q tile is one contiguous Ls x 128-byte block)
+    qh = torch.randn(Lo, 3 * H, B, Ls, 64, device="cuda").bfloat16()
+    fh = lambda: ops.favor_attention(qh, pc, o, (Ls * 64, 3 * H * B * Ls * 64, 64, B * Ls * 64), (RB * inner, so * inner, ss * inner), 0, H * B * Ls * 64, 2 * H * B * Ls * 64, B, Lo, H, Ls, 64, 266, not gen, 1e-3 if gen else 1e-4)
+    t = timeit(fh)
+    print(f"   head-major q|k|v tiles: {t*1e3:.0f} us, {fl/t/1e9:.0f} TF/s", flush=True)
+    if int(os.environ.get("RF_FAVOR_DBG", "0")) & 8:
+        import ctypes as C
+        buf = (C.c_ulonglong * 7)()
+        ops.lib.rf_favor_phase_cycles.argtypes = [C.c_void_p, C.c_int]
+        ops.lib.rf_favor_phase_cycles(None, 1)
+        f(); torch.cuda.synchronize()
+        ops.lib.rf_favor_phase_cycles(buf, 1)
+        n = max(buf[6], 1)
+        names = ["wait K/V", "phase A", "publish + barrier", "prefetch issue + combine", "phase B", "stores"]
+        print("   cycles per item (wave 0): " + ", ".join(f"{nm} {buf[i]/n:.0f}" for i, nm in enumerate(names)) + f"  [{n} items]")
