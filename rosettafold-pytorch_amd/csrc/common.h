@@ -19,6 +19,15 @@ __device__ __forceinline__ bf16_t f2bf(float x) {
   return __builtin_bit_cast(bf16_t, b);
 }
 
+// two floats -> packed bf16 pair (low half = a): ONE v_cvt_pk_bf16_f32.  (f2bf(a) | f2bf(b) << 16 compiles to two
+// conversions plus a shift and an or.)
+typedef __attribute__((ext_vector_type(2))) float rf_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 rf_bf16x2;
+__device__ __forceinline__ unsigned rf_pack2_bf16(float a, float b) {
+  const rf_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, rf_bf16x2));
+}
+
 // dtype-generic scalar load/store (T = activation dtype chosen by the host: fp32 or bf16)
 __device__ __forceinline__ float ld(const void* p, int dtype, int64_t i) {
   return dtype == RF_F32 ? ((const float*)p)[i] : bf2f(((const bf16_t*)p)[i]);

@@ -65,7 +65,7 @@ __device__ __forceinline__ void fv_load_tile(char* smem, int lds_off, const bf16
   }
 }
 
-__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ __forceinline__ unsigned pack2(float a, float b) { return rf_pack2_bf16(a, b); }
 __device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }
 
 union Frag {

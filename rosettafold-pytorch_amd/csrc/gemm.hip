@@ -374,8 +374,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_bf16_kernel(const Gemm
                   *(float4*)(lrow + nl * 4) = make_float4(v0, v1, v2, v3);
                 } else {
                   uint2 o;
-                  o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-                  o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                  o.x = rf_pack2_bf16(v0, v1);
+                  o.y = rf_pack2_bf16(v2, v3);
                   *(uint2*)(lrow + nl * 2) = o;
                 }
               }
@@ -394,8 +394,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_bf16_kernel(const Gemm
                   *(float4*)(lrow + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                   uint2 o;
-                  o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                  o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                  o.x = rf_pack2_bf16(v[0], v[1]);
+                  o.y = rf_pack2_bf16(v[2], v[3]);
                   *(uint2*)(lrow + nl * 2) = o;
                 }
               }
@@ -603,8 +603,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
           *(float4*)((float*)d.C + o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
           uint2 w;
-          w.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-          w.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+          w.x = rf_pack2_bf16(v[0], v[1]);
+          w.y = rf_pack2_bf16(v[2], v[3]);
           *(uint2*)((bf16_t*)d.C + o) = w;
         }
         continue;

@@ -310,8 +310,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
                 *(f32x4*)(lrow + nl * 4) = (f32x4){v0, v1, v2, v3};
               } else {
                 uint2 o;
-                o.x = (unsigned)f2bf(v0) | ((unsigned)f2bf(v1) << 16);
-                o.y = (unsigned)f2bf(v2) | ((unsigned)f2bf(v3) << 16);
+                o.x = rf_pack2_bf16(v0, v1);
+                o.y = rf_pack2_bf16(v2, v3);
                 *(uint2*)(lrow + nl * 2) = o;
               }
             }
@@ -403,8 +403,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (acc[i][j][e] - ln_mean[i]) * ln_rstd[i] * g4[e] + b4[e];
           uint2 w;
-          w.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-          w.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+          w.x = rf_pack2_bf16(o[0], o[1]);
+          w.y = rf_pack2_bf16(o[2], o[3]);
           *(uint2*)(lrow + (j * 16 + 4 * fq) * 2) = w;
         }
         asm volatile("" ::: "memory");

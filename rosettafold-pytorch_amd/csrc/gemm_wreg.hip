@@ -44,7 +44,7 @@ __device__ __forceinline__ void wreg_glds16(const void* src, void* lds_wave_base
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ unsigned wreg_pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ __forceinline__ unsigned wreg_pack2(float a, float b) { return rf_pack2_bf16(a, b); }
 
 // KS: K / 32;  TMR: rows per activation tile;  WR: wave rows (8 / WR wave columns);  WCT: 16-column tiles per wave;
 // NSTG: ring depth;  CS: split-C addressing

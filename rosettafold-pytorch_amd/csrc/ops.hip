@@ -38,8 +38,8 @@ __device__ __forceinline__ void st4(void* p, int dt, int64_t e, float4 v) {
     *(float4*)((float*)p + e) = v;
   } else {
     uint2 w;
-    w.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-    w.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+    w.x = rf_pack2_bf16(v.x, v.y);
+    w.y = rf_pack2_bf16(v.z, v.w);
     *(uint2*)((bf16_t*)p + e) = w;
   }
 }
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int6
             *(float4*)((float*)y + row * y_ld + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
           } else {
             uint2 w;
-            w.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-            w.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+            w.x = rf_pack2_bf16(o[0], o[1]);
+            w.y = rf_pack2_bf16(o[2], o[3]);
             *(uint2*)((bf16_t*)y + row * y_ld + 4 * c) = w;
           }
         }
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256) void layernorm_rows8_kernel(const float* x, in
         *(float4*)((float*)y + row * y_ld + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
       } else {
         uint2 w;
-        w.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-        w.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+        w.x = rf_pack2_bf16(o[0], o[1]);
+        w.y = rf_pack2_bf16(o[2], o[3]);
         *(uint2*)((bf16_t*)y + row * y_ld + 4 * c) = w;
       }
     }
@@ -307,10 +307,10 @@ __global__ __launch_bounds__(256) void layernorm_vec_bf16_kernel(const bf16_t* x
           *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
         } else {
           uint4 w;
-          w.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-          w.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
-          w.z = (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16);
-          w.w = (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16);
+          w.x = rf_pack2_bf16(o[0], o[1]);
+          w.y = rf_pack2_bf16(o[2], o[3]);
+          w.z = rf_pack2_bf16(o[4], o[5]);
+          w.w = rf_pack2_bf16(o[6], o[7]);
           *(uint4*)((bf16_t*)y + row * y_ld + 8 * c) = w;
         }
       }
@@ -361,8 +361,8 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* x, i
         *(float4*)((float*)y + row * y_ld + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
       } else {
         uint2 w;
-        w.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-        w.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+        w.x = rf_pack2_bf16(o[0], o[1]);
+        w.y = rf_pack2_bf16(o[2], o[3]);
         *(uint2*)((bf16_t*)y + row * y_ld + 4 * c) = w;
       }
     }
@@ -753,10 +753,10 @@ __global__ __launch_bounds__(256) void instnorm_apply_vec_kernel(const bf16_t* x
         *(float4*)((float*)dst + e0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
       } else {
         uint4 w;
-        w.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-        w.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
-        w.z = (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16);
-        w.w = (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16);
+        w.x = rf_pack2_bf16(o[0], o[1]);
+        w.y = rf_pack2_bf16(o[2], o[3]);
+        w.z = rf_pack2_bf16(o[4], o[5]);
+        w.w = rf_pack2_bf16(o[6], o[7]);
         *(uint4*)((bf16_t*)dst + e0) = w;
       }
     };

@@ -46,7 +46,7 @@ __device__ __forceinline__ void outer_glds16(const void* src, void* lds_wave_bas
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-__device__ __forceinline__ unsigned outer_pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ __forceinline__ unsigned outer_pack2(float a, float b) { return rf_pack2_bf16(a, b); }
 // workgroup barrier that publishes this wave's LDS writes but leaves its DMAs in flight (a __syncthreads() would drain them)
 __device__ __forceinline__ void outer_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

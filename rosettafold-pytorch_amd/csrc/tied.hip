@@ -27,7 +27,7 @@ union TFrag {
 };
 typedef __attribute__((ext_vector_type(4))) short ts16x4;
 
-__device__ __forceinline__ unsigned tpack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ __forceinline__ unsigned tpack2(float a, float b) { return rf_pack2_bf16(a, b); }
 
 __device__ __forceinline__ void tied_glds16(const void* src, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
