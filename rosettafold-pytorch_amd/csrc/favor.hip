@@ -695,20 +695,21 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
       }
     }
     FV_STAMP(1)
-    // combine the two sequence halves through the ctx^T image: half 1 publishes, half 0 adds and republishes
-    if (hs == 1) {
+    // Combine the two sequence halves through the ctx^T image, the work split between them: feature tiles j = 2, 3 of a
+    // group are finished by the wave of half 1, the others by half 0.  Each wave first publishes its partials of the
+    // tiles its partner finishes, then (after the barrier) adds the partner's partials to its own tiles and republishes.
+    auto mine = [&](int j) { return ((j >> 1) & 1) == hs; };
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
-        if (j < nm) {
+    for (int j = 0; j < 5; ++j)
+      if (j < nm && !mine(j)) {
 #pragma unroll
-          for (int i = 0; i < FV_DT; ++i) {
-            uint2 w;
-            w.x = pack2(ctx[j][i][0], ctx[j][i][1]);
-            w.y = pack2(ctx[j][i][2], ctx[j][i][3]);
-            *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq)) = w;
-          }
+        for (int i = 0; i < FV_DT; ++i) {
+          uint2 w;
+          w.x = pack2(ctx[j][i][0], ctx[j][i][1]);
+          w.y = pack2(ctx[j][i][2], ctx[j][i][3]);
+          *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq)) = w;
         }
-    }
+      }
     fv_lds_barrier();  // every wave is through phase A: the K and V tiles are free again
     FV_STAMP(2)
     // Pin the Q fragments here (loaded a whole phase ago): hipcc's own wait for them lands at this point, BEFORE the
@@ -728,29 +729,21 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
         load_tile8(V_OFF, p.qkv + xb2 + p.v_off, p.x_s, LS_TAG);
       }
     }
-    if (hs == 0) {
-      // all partner partials first (independent reads in flight together), then add and republish: a read-modify-write
-      // per tile would be a chain of 25 LDS round trips
-      uint2 o[5][FV_DT];
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
-        if (j < nm) {
+    for (int j = 0; j < 5; ++j)
+      if (j < nm && mine(j)) {
+        // the tile's five partner partials first (independent reads in flight together), then add and republish
+        uint2 o[FV_DT];
 #pragma unroll
-          for (int i = 0; i < FV_DT; ++i)
-            o[j][i] = *(const uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq));
+        for (int i = 0; i < FV_DT; ++i) o[i] = *(const uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq));
+#pragma unroll
+        for (int i = 0; i < FV_DT; ++i) {
+          uint2 w;
+          w.x = pack2(ctx[j][i][0] + bf2f((bf16_t)(o[i].x & 0xffff)), ctx[j][i][1] + bf2f((bf16_t)(o[i].x >> 16)));
+          w.y = pack2(ctx[j][i][2] + bf2f((bf16_t)(o[i].y & 0xffff)), ctx[j][i][3] + bf2f((bf16_t)(o[i].y >> 16)));
+          *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq)) = w;
         }
-#pragma unroll
-      for (int j = 0; j < 5; ++j)
-        if (j < nm) {
-#pragma unroll
-          for (int i = 0; i < FV_DT; ++i) {
-            uint2 w;
-            w.x = pack2(ctx[j][i][0] + bf2f((bf16_t)(o[j][i].x & 0xffff)), ctx[j][i][1] + bf2f((bf16_t)(o[j][i].x >> 16)));
-            w.y = pack2(ctx[j][i][2] + bf2f((bf16_t)(o[j][i].y & 0xffff)), ctx[j][i][3] + bf2f((bf16_t)(o[j][i].y >> 16)));
-            *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq)) = w;
-          }
-        }
-    }
+      }
     fv_lds_barrier();  // ctx^T complete
 
     FV_STAMP(3)
