@@ -98,15 +98,20 @@ def profile_gemms(model, inputs):
         torch.cuda.synchronize()
     finally:
         ops.lib.rf_gemm = orig
+    tab = {}
+    for s, e, fl, fam, M, N, K, nb, nbytes in recs:
+        t = tab.setdefault((fam, M, N, K, nb), [0.0, 0.0, 0, 0.0])
+        t[0] += s.elapsed_time(e) * 1e-3
+        t[1] += fl
+        t[2] += 1
+        t[3] += nbytes
+    shapes = []
+    for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])[:12]:
+        shapes.append({"kernel": FAMILY.get(k[0], str(k[0])).split(" ")[0], "M": k[1], "N": k[2], "K": k[3], "batch": k[4],
+                       "launches": v[2], "avg_launch_ms": 1e3 * v[0] / v[2], **bound_of(v[1], v[3], v[0])})
     if os.environ.get("RF_GEMM_TABLE"):
-        tab = {}
-        for s, e, fl, fam, M, N, K, nb, _ in recs:
-            t = tab.setdefault((fam, M, N, K, nb), [0.0, 0.0, 0])
-            t[0] += s.elapsed_time(e)
-            t[1] += fl
-            t[2] += 1
         for k, v in sorted(tab.items(), key=lambda kv: -kv[1][0])[:40]:
-            log("gemm family=%d M=%d N=%d K=%d batch=%d : %d calls %.2f ms total, %.0f TF/s" % (*k, v[2], v[0], v[1] / v[0] / 1e9))
+            log("gemm family=%d M=%d N=%d K=%d batch=%d : %d calls %.2f ms total, %.0f TF/s" % (*k, v[2], 1e3 * v[0], v[1] / v[0] / 1e12))
     fams = {}
     for s, e, fl, fam, M, N, K, nb, nbytes in recs:
         f = fams.setdefault(FAMILY.get(fam, f"family {fam}"), [0.0, 0.0, 0, 0.0])
@@ -114,7 +119,21 @@ def profile_gemms(model, inputs):
         f[1] += fl
         f[2] += 1
         f[3] += nbytes
-    return fams
+    return fams, shapes
+
+
+HBM_PEAK_GBPS = 8000.0
+
+
+def bound_of(flops, nbytes, secs):
+    """Which roof an (algorithmic flops, algorithmic bytes) pair sits under on MI355X: the ridge is peak_flops / peak_bw
+    = 2.5e15 / 8e12 = 312 FLOP/byte; below it the HBM roof is the lower one."""
+    tf, gbps = flops / secs / 1e12, nbytes / secs / 1e9
+    if flops / max(nbytes, 1.0) < 1e3 * MFMA_BF16_PEAK_TFLOPS / HBM_PEAK_GBPS:
+        return {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                "flop_per_byte": flops / max(nbytes, 1.0), "tflops": tf}
+    return {"bound": "mfma", "achieved": tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_BF16_PEAK_TFLOPS,
+            "flop_per_byte": flops / max(nbytes, 1.0), "algorithmic_GBps": gbps}
 
 
 def log(msg):
@@ -318,7 +337,7 @@ def main():
         }
         full = args.config == 2 and args.dtype == "bf16"
         if world == 1 and full and not args.no_roofline:
-            fams = profile_gemms(model, inputs)
+            fams, shapes = profile_gemms(model, inputs)
             name, (secs, flops, n, nbytes) = max(fams.items(), key=lambda kv: kv[1][0])
             traffic, tnote = None, "no PMC collection for this tree (tools/pmc_traffic.py)"
             try:
@@ -331,14 +350,18 @@ def main():
                     tnote = f"stale: profiles/r02_traffic_pmc.json was collected on tree {pm.get('tree')}, this is {tree_hash()}"
             except (OSError, KeyError, ValueError):
                 pass
-            res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": flops / secs / 1e12,
-                               "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": flops / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+            # the roof the dominant kernel sits under is chosen by its arithmetic intensity (algorithmic FLOP per algorithmic
+            # byte against the 312 FLOP/byte ridge); the other roof's fraction is reported beside it
+            b = bound_of(flops, nbytes, secs)
+            res["roofline"] = {"bound": b["bound"], "kernel": name, "achieved": b["achieved"], "peak": b["peak"],
+                               "unit": b["unit"], "frac": b["frac"], "traffic": traffic,
                                "traffic_source": tnote, "launches": n, "avg_launch_ms": 1e3 * secs / n,
+                               "flop_per_byte": b["flop_per_byte"],
                                "algorithmic_gflop_per_launch": flops / n / 1e9,
                                "algorithmic_bytes_per_launch": nbytes / n,
-                               "algorithmic_hbm_GBps": nbytes / secs / 1e9, "hbm_peak_GBps": 8000.0,
-                               "share_of_step": secs / (dt / args.steps),
+                               "mfma_TFLOPs": flops / secs / 1e12, "mfma_frac": flops / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                               "algorithmic_hbm_GBps": nbytes / secs / 1e9, "hbm_frac": nbytes / secs / 1e9 / HBM_PEAK_GBPS,
+                               "share_of_step": secs / (dt / args.steps), "shapes": shapes,
                                "families": {k: {"s": v[0], "tflops": v[1] / max(v[0], 1e-12) / 1e12, "n": v[2],
                                                 "algorithmic_GBps": v[3] / max(v[0], 1e-12) / 1e9}
                                             for k, v in fams.items()}}
