@@ -69,15 +69,18 @@ def msa_embedding(P, pre, msa, aa_idx, max_len):
     return x + P[pre + ".query_enc.weight"][qidx][None, :, None, :]
 
 
-def pair_embedding(P, pre, seq, aa_idx, max_len):
-    """rf.py:123-181 + rf.py:79-103 (use_template=False)."""
+def pair_embedding(P, pre, seq, aa_idx, max_len, template=None):
+    """rf.py:123-181 + rf.py:79-103; template [B,L,L,d_template] selects the use_template branch (rf.py:161-169)."""
     L = seq.shape[-1]
     e = P[pre + ".embed_seq.weight"][seq]  # [B,L,d/2]
     left = e[:, None, :, :].expand(-1, L, -1, -1)  # left[b,i,j] = e[b,j]
     right = e[:, :, None, :].expand(-1, -1, L, -1)  # right[b,i,j] = e[b,i]
     dist = aa_idx.unsqueeze(-1) - aa_idx.unsqueeze(-2)
     sep = torch.log(torch.abs(dist) + 1).unsqueeze(-1)
-    x = _lin(P, pre + ".proj", torch.cat([left, right, sep], -1))
+    feats = [left, right, sep]
+    if template is not None:
+        feats.append(_ln(P, pre + ".ln_template", template))
+    x = _lin(P, pre + ".proj", torch.cat(feats, -1))
     dh = e.shape[-1]
     pe = sinusoid_table(dh, max_len)[aa_idx]  # [B,L,dh]
     pe_row = pe[:, :, None, :].expand(-1, -1, L, -1)

@@ -335,7 +335,9 @@ class MsaEmbedding(RFModule):
 
 
 class PairEmbedding(RFModule):
-    """rf.py:123-181 (use_template=False path; the 289->d_pair Linear is folded into two 21-row tables)."""
+    """rf.py:123-181.  The (d_pair+1 [+d_template]) -> d_pair Linear is split by input block: the two sequence-embedding
+    blocks fold into two 21-row tables, the separation column into one vector (rf_pair_embed), and with use_template
+    the LayerNorm'ed template block (rf.py:141-143,161-169) is one rf_gemm accumulated onto that result."""
 
     def __init__(self, d_input=21, d_pair=288, max_len=260, p_pe_drop=0.1, use_template=False, d_template=64):
         super().__init__()
@@ -344,16 +346,21 @@ class PairEmbedding(RFModule):
         self.pos_enc = SinusoidalPositionalEncoding2D(d_pair, max_len, p_pe_drop)
         self.use_template = use_template
         if use_template:
-            raise NotImplementedError("template branch (rf.py:141-169) is outside the forward path (SURVEY 8(f))")
-        self.proj = Linear(d_pair + 1, d_pair)
+            self.ln_template = LayerNorm(d_template)
+            self.proj = Linear(d_pair + d_template + 1, d_pair)
+        else:
+            self.proj = Linear(d_pair + 1, d_pair)
 
     def forward(self, seq, aa_idx, template=None):
-        if template is not None:
+        if not self.use_template and template is not None:
             raise ValueError(f"[{self.__class__.__name__}]: template is not None but use_template is False")
+        if self.use_template and template is None:
+            # the reference fails inside nn.LayerNorm(None) (rf.py:166); same exception type, clearer text
+            raise TypeError(f"[{self.__class__.__name__}]: use_template is True but no template was given")
         check_index_range(None, seq.contiguous(), aa_idx.contiguous(), self.embed_seq.num_embeddings, self.pos_enc.max_len)
-        return self.run(seq, aa_idx)
+        return self.run(seq, aa_idx, template)
 
-    def run(self, seq, aa_idx):
+    def run(self, seq, aa_idx, template=None):
         """(indices already validated)"""
         h = self.half_d_pair
 
@@ -365,7 +372,15 @@ class PairEmbedding(RFModule):
             return tl, tr, w[:, 2 * h].contiguous()
 
         tl, tr, wsep = self.cached("tables", tables)
-        return ops.pair_embed(seq.contiguous(), aa_idx.contiguous(), tl, tr, wsep, _f(self.proj.bias), self.pos_enc.pos_enc)
+        x = ops.pair_embed(seq.contiguous(), aa_idx.contiguous(), tl, tr, wsep, _f(self.proj.bias), self.pos_enc.pos_enc)
+        if self.use_template:
+            B, Lr = seq.shape
+            if tuple(template.shape[:3]) != (B, Lr, Lr) or template.shape[-1] != self.ln_template.weight.shape[0]:
+                raise ValueError(f"[{self.__class__.__name__}]: template must be [B, L, L, {self.ln_template.weight.shape[0]}]")
+            wt = self.cached("wtempl", lambda: self.proj.weight.detach()[:, 2 * h + 1:].to(T()).contiguous())
+            tn = ln(self.ln_template, template.float().contiguous())
+            ops.linear(tn, wt, None, out=x, residual=x)  # x += LayerNorm(template) @ W_template^T (fp32, in place)
+        return x
 
 
 # ================================================================================================

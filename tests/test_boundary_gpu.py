@@ -217,3 +217,22 @@ def test_ops_refuse_a_foreign_device_context():
     x = torch.zeros(8, 8, device="cuda:1")
     with torch.cuda.device(0), pytest.raises(_lib.RfmiError):
         ops.fill(x, 1.0)
+
+
+def test_a3m_to_pdb_end_to_end():
+    """alignment text -> model inputs -> HIP forward -> decoded maps and a PDB backbone."""
+    from rosettafold_pytorch_amd import featurize as F
+    a3m = ">q\nMKVLAAGIVGLSEERARELA\n>h1\nMKVLAtAGIVGLSEDRARELA\n>h2\n-KVLSAGIVGL-EERARDLA\n"
+    msa, seq, aa = F.featurize(a3m, chain_lengths=[12, 8], device=DEV, max_len=260)
+    assert msa.shape == (1, 3, 20) and int(aa.max()) == 219
+    torch.manual_seed(3)
+    m = R.RoseTTAFold(d_input=21, d_msa=96, d_pair=72, d_node=8, d_edge=8, d_state=8, n_two_track_blocks=1,
+                      n_three_track_blocks=2, n_encoder_layers=1, max_len=260, n_neighbors=[128, 128], p_dropout=0.0).to(DEV)
+    logits, xyz, plddt = m(msa, seq, aa)
+    d = F.decode_logits(logits)
+    assert d["p_contact"].shape == (1, 20, 20) and torch.isfinite(d["dist_expected"]).all()
+    assert (d["p_contact"] >= 0).all() and (d["p_contact"] <= 1 + 1e-5).all()
+    assert (d["phi"] >= 0).all() and (d["phi"] <= 3.1416).all() and (d["omega"].abs() <= 3.1416).all()
+    txt = F.to_pdb(xyz[0], seq[0], torch.sigmoid(plddt[0]), aa_idx=aa[0], chain_lengths=[12, 8])
+    x2, s2, _ = F.from_pdb_backbone(txt)
+    assert torch.allclose(x2, xyz[0].cpu(), atol=1e-3) and torch.equal(s2, seq[0].cpu())

@@ -270,6 +270,53 @@ def _run_full(cfg):
     return logits, xyz, plddt, errs, agree
 
 
+def test_pair_embedding_template(mode):
+    """use_template=True branch of the public module (rf.py:141-169): against the oracle and against the vector captured
+    from the reference itself (tests/golden/pair_embedding_template.npz)."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "pair_embedding_template.npz"))
+    seq, aa, templ = (torch.from_numpy(z["in:" + k]) for k in ("seq", "aa_idx", "template"))
+    m = R.PairEmbedding(21, 32, 40, 0.0, use_template=True, d_template=16).to(DEV)
+    m.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w:")})
+    y = m(seq.to(DEV), aa.to(DEV), templ.to(DEV))
+    assert rel(y, torch.from_numpy(z["out:y"])) < (2e-5 if mode[0] == torch.float32 else 8e-3)
+    assert rel(y, O.pair_embedding(state(m), "m", seq, aa, 40, template=templ)) < (2e-5 if mode[0] == torch.float32 else 8e-3)
+    with pytest.raises(TypeError):  # the reference raises inside LayerNorm(None), rf.py:166
+        m(seq.to(DEV), aa.to(DEV))
+    with pytest.raises(ValueError):
+        m(seq.to(DEV), aa.to(DEV), templ[:, :5].to(DEV))
+
+
+def test_blocks(mode):
+    """a20: TwoTrackBlock / ThreeTrackBlock / FinalBlock on their own (rf.py:923-1127) against the oracle's block functions."""
+    msa, pair = rn(B, N, Lr, DM, seed=1), rn(B, Lr, Lr, DP, seed=2)
+    xyz = xyz_trace(B, Lr)
+    g = torch.Generator().manual_seed(9)
+    seq = torch.randint(0, 21, (B, Lr), generator=g)
+    onehot = torch.nn.functional.one_hot(seq, 21).float()
+    fp32 = mode[0] == torch.float32
+    two = build(lambda: R.TwoTrackBlock(DM, DP, 1, 0.0))
+    m2, p2 = two(msa.to(DEV), pair.to(DEV))
+    rm, rp = O.two_track_block(state(two), "m", msa, pair, 1)
+    assert rel(m2, rm) < (2e-4 if fp32 else 4e-2) and rel(p2, rp) < (2e-4 if fp32 else 4e-2)
+    three = build(lambda: R.ThreeTrackBlock(DM, DP, DN, DE, DS, 1, 128, 0.0))
+    m3, p3, x3 = three(msa.to(DEV), pair.to(DEV), xyz.to(DEV), onehot.to(DEV), AA.to(DEV))
+    rm, rp, rx = O.three_track_block(state(three), "m", msa, pair, xyz, onehot, AA, 1, 128, DS)
+    if fp32:  # the bf16 path crosses the structure module's discontinuities (test_coord_update): robust bound only
+        assert rel(m3, rm) < 5e-4 and rel(p3, rp) < 5e-4 and rel(x3, rx) < 5e-4
+    else:
+        assert rel2(m3, rm) < 0.1 and rel2(p3, rp) < 0.05 and rel2(x3, rx) < 0.3
+    fin = build(lambda: R.FinalBlock(DM, DP, DN, DE, DS, 1, 0.0))
+    m4, p4, x4, pl = fin(msa.to(DEV), pair.to(DEV), xyz.to(DEV), onehot.to(DEV), AA.to(DEV))
+    rm, rp, rx, rpl = O.three_track_block(state(fin), "m", msa, pair, xyz, onehot, AA, 1, 32, DS, final=True)
+    assert m4.shape == (B, N, Lr, DM) and p4.shape == (B, Lr, Lr, DP) and x4.shape == (B, Lr, 3, 3) and pl.shape == (B, Lr)
+    if fp32:
+        assert rel(m4, rm) < 5e-4 and rel(p4, rp) < 5e-4 and rel(x4, rx) < 5e-4 and rel(pl, rpl) < 5e-4
+    else:
+        assert rel2(p4, rp) < 0.05 and rel2(x4, rx) < 0.3 and rel2(pl, rpl) < 0.3
+
+
 def test_full_model_shapes_and_parity(mode):
     """reference tests/test_module.py:792-824 (shape contract) + value parity with the oracle."""
     logits, xyz, plddt, errs, agree = _run_full(CFG)

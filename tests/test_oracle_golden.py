@@ -28,6 +28,12 @@ def close(a, b, rtol=1e-4, atol=1e-5):
     torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
 
 
+def test_pair_embedding_template(golden_dir):
+    """use_template=True branch (rf.py:141-169)."""
+    P, I, Y, X = load(golden_dir, "pair_embedding_template")
+    close(O.pair_embedding(pre(P, "m"), "m", I["seq"], I["aa_idx"], int(X["max_len"]), template=I["template"]), Y["y"])
+
+
 def test_msa_embedding(golden_dir):
     P, I, Y, X = load(golden_dir, "msa_embedding")
     close(O.msa_embedding(pre(P, "m"), "m", I["msa"], I["aa_idx"], int(X["max_len"])), Y["y"])

@@ -11,7 +11,10 @@
     to fp16-representable values BEFORE the reference runs and stored as fp16 (exact); the pair output is stored on a
     stride-2 sub-grid to bound the fixture size.
 
-    python tools/make_goldens_r2.py
+  * pair_embedding_template.npz -- PairEmbedding(use_template=True) (rf.py:141-169), the branch of the public module
+    that RoseTTAFold.forward itself never takes.
+
+    python tools/make_goldens_r2.py [--only template]
 """
 import os
 import sys
@@ -74,6 +77,18 @@ def main():
     import rosettafold_pytorch.rosettafold_pytorch as rf
 
     torch.set_grad_enabled(False)
+    # ---- template branch of PairEmbedding
+    g = torch.Generator().manual_seed(77)
+    B, L, dp, dt = 2, 12, 32, 16
+    seq = torch.randint(0, 21, (B, L), generator=g)
+    aa_idx = torch.stack([torch.arange(L), torch.arange(L) * 2 + 3])
+    templ = torch.randn(B, L, L, dt, generator=g)
+    torch.manual_seed(5)
+    m = rf.PairEmbedding(d_input=21, d_pair=dp, max_len=40, p_pe_drop=0.0, use_template=True, d_template=dt).eval()
+    MG.save("pair_embedding_template", m, {"seq": seq, "aa_idx": aa_idx, "template": templ}, {"y": m(seq, aa_idx, templ)},
+            {"max_len": 40})
+    if "--only" in sys.argv and sys.argv[sys.argv.index("--only") + 1] == "template":
+        return
     # ---- state_dict manifests
     readme = dict(d_input=21, d_msa=384, d_pair=288, d_node=32, d_edge=32, d_state=32, n_two_track_blocks=8,
                   n_three_track_blocks=5, n_encoder_layers=4, max_len=260, n_neighbors=[128, 128, 64, 64, 64],
