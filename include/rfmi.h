@@ -140,10 +140,15 @@ int rf_tied_av(const void* att, const void* v, const int64_t v_strides[4], void*
  *   att[b,h,i,:] = softmax_j( sum_{n,d} (w[b,h,n,i] * qscale) q[b,n,h,i,d] k[b,n,h,j,d] ),  out = att . v
  * q / k share qk_strides {b,n,h,l}; w (fp32, may be NULL = q already scaled) has strides {b,h,n} with l contiguous: the
  * position weights of rf.py:252 are applied inside the logits kernel instead of a pass over q.  att: bf16 [B,H,L,L]
- * (caller-owned workspace and result); att_sym as in rf_tied_softmax (may be NULL). */
+ * (caller-owned workspace and result); att_sym as in rf_tied_softmax (may be NULL).
+ * partial_ws (may be NULL): fp32 workspace of partial_ws_elems elements.  With L == 256 and at least
+ * 2 * B*H*L*L elements (4 * B*H*L*L when N > 128) the logits run contraction-split: workgroups of 128 query rows x 256
+ * keys over ranges of <= 64 MSA rows write fp32 partial logits there and a second kernel adds them and takes the row
+ * softmax (0.6x the L2 -> LDS bytes of the one-pass kernel).  Without it, or for other shapes, the one-pass kernel runs. */
 int rf_tied_attention(const void* q, const void* k, const void* v, const int64_t qk_strides[4], const int64_t v_strides[4],
                       const float* w, const int64_t w_strides[3], float qscale, void* att, float* att_sym, int64_t sym_ld,
-                      void* out, const int64_t o_strides[4], int B, int H, int N, int L, int d_head, void* stream);
+                      void* out, const int64_t o_strides[4], int B, int H, int N, int L, int d_head, float* partial_ws,
+                      int64_t partial_ws_elems, void* stream);
 
 /* PositionWiseWeightFactor in collapsed form on the matrix pipe (rf.py:205-217):
  *   w[b,h,n,l] = softmax_n( scale * sum_c xn[b,n,l,c] * u[b,l,h,c] ),   u[b,l,h,:] = W_k[h*dh:(h+1)*dh, :]^T to_q(x_0)[b,l,h,:]

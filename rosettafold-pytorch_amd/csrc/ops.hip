@@ -1354,5 +1354,5 @@ extern "C" int rf_add_pos_enc(const float* x, const int64_t* aa_idx, const float
   return rf_launch_status();
 }
 
-extern "C" int rf_version(void) { return 2; }
+extern "C" int rf_version(void) { return 3; }
 extern "C" const char* rf_build_info(void) { return "librfmi gfx950 (MI355X) round-2"; }

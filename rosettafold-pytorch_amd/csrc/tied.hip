@@ -46,6 +46,7 @@ struct TiedP {
   float qscale;                                     // multiplies w (d_head^-0.5, rf.py:252)
   bf16_t* att;                                      // [B, H, L, L]
   int B, H, N;
+  int dbg;  // timing experiments (RF_TIED_DBG; results are WRONG when set): 1 no DMA after the prologue, 2 fragments read once, 4 no MFMA
 };
 
 template <int L, bool SCALE>
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void tied_logits_kernel(const TiedP p) {
   const int64_t lane_off = (int64_t)lrow * p.l_stride + c_log * 8;
   auto stage = [&](int n) {
     char* st = smem + (n % NSTG) * STAGE;
-    const bool live = n < p.N;
+    const bool live = n < p.N && !((p.dbg & 1) && n >= NSTG - 1);
 #pragma unroll
     for (int t = 0; t < PW; ++t) {
       const int instr = t * 4 + wave;
@@ -119,20 +120,24 @@ __global__ __launch_bounds__(256) void tied_logits_kernel(const TiedP p) {
     stage(n + NSTG - 1);  // into the buffer of step n-1, whose fragments every wave has consumed
     const char* st = smem + (n % NSTG) * STAGE;
     TFrag qf;
-    qf.v = *(const bf16x8*)(st + q_rd);
     bf16x8 kf[JT];
+    if (!(p.dbg & 2) || n == 0) {
+      qf.v = *(const bf16x8*)(st + q_rd);
 #pragma unroll
-    for (int j = 0; j < JT; ++j) kf[j] = *(const bf16x8*)(st + k_rd + j * 1024);
+      for (int j = 0; j < JT; ++j) kf[j] = *(const bf16x8*)(st + k_rd + j * 1024);
+    }
     if constexpr (SCALE) {
       const float ws = wrow[n * 64] * p.qscale;  // w[b,h,n, row of this lane] * d_head^-0.5: the same rounding point as q*w (rf.py:252)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         qf.u[e] = tpack2(__uint_as_float(qf.u[e] << 16) * ws, __uint_as_float(qf.u[e] & 0xffff0000u) * ws);
     }
+    if (!(p.dbg & 4)) {
 #pragma unroll
-    for (int j = 0; j < JT; ++j)
-      // key tile as MFMA-A, query tile as MFMA-B: lane holds logits[i = fr][j = 16*tile + 4*fq .. +3]
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j], qf.v, acc[j], 0, 0, 0);
+      for (int j = 0; j < JT; ++j)
+        // key tile as MFMA-A, query tile as MFMA-B: lane holds logits[i = fr][j = 16*tile + 4*fq .. +3]
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j], qf.v, acc[j], 0, 0, 0);
+    }
   }
 
   // ---- row softmax: a row lives in the four lanes {fr, fr+16, fr+32, fr+48} ------------------------------------
@@ -177,6 +182,157 @@ __global__ __launch_bounds__(256) void tied_logits_kernel(const TiedP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Contraction-split form of the logits (L = 256): a workgroup owns 128 query rows x all 256 keys of one (b, h) over a
+// RANGE of the MSA rows n and writes fp32 partial logits; tied_split_softmax_kernel adds the partials and takes the row
+// softmax.  Why: the 64-row kernel above is bound by its L2 -> LDS stream (20 KB per contraction step for 64 x 256
+// outputs: 500 MB per launch at ~7 TB/s; RF_TIED_DBG ablation: 70 of its 90 us remain with the fragment reads and the
+// MFMAs switched off).  Here a step moves 24 KB for 128 x 256 outputs (0.6x the bytes per FLOP), eight waves of 64 x 64
+// read 8 fragments for 16 MFMAs instead of 17, and the split over n keeps >= 192 workgroups in flight.
+// ------------------------------------------------------------------------------------------------------------------
+#define TIED_SPLIT_NSTG 5  // ring stages of 24 KB: the stream is latency-bound (~2 us per piece under load), bytes in flight = rate
+struct TiedSplitP {
+  const bf16_t* q;
+  const bf16_t* k;
+  int64_t b_stride, n_stride, h_stride, l_stride;
+  const float* w;
+  int64_t w_b, w_h, w_n;
+  float qscale;
+  float* part;          // fp32 [nsplit][B][H][256][256]
+  int64_t split_stride; // elements between the partial tensors of consecutive splits
+  int B, H, N, nsplit, nper;  // nper = MSA rows per split (N = nsplit * nper)
+  int dbg;                    // RF_TIED_DBG (results WRONG when set): 2 fragments read once, 4 no MFMA, 8 no partial stores
+};
+
+template <bool SCALE>
+__global__ __launch_bounds__(512) void tied_logits_split_kernel(const TiedSplitP p) {
+  constexpr int L = 256, RB = 128, NSTG = TIED_SPLIT_NSTG;
+  constexpr int Q_BYTES = RB * 64, K_BYTES = L * 64, STAGE = Q_BYTES + K_BYTES;
+  constexpr int QI = RB / 16, PW = 3;        // (QI + L / 16) DMA pieces of 1 KB per stage = 3 per wave, no padding
+  static_assert(QI + L / 16 == 8 * PW, "pieces per stage");
+  constexpr int DUMP = NSTG * STAGE;
+  constexpr int W_OFF = DUMP + 1024;         // [nper][128] fp32 position weights of this workgroup's query rows
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;   // 64-query half, 64-key quarter
+  const int fr = lane & 15, fq = lane >> 4;
+
+  // XCD-aware order: the 2 * nsplit workgroups of one (b, h) run on the same XCD (they share q / k slabs through its L2)
+  int lid;
+  {
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+    lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int rb = lid & 1, sp = (lid >> 1) % p.nsplit;
+  const int bh = lid / (2 * p.nsplit), h = bh % p.H, b = bh / p.H;
+  const int n0 = sp * p.nper;
+  const bf16_t* qb = p.q + (int64_t)b * p.b_stride + (int64_t)h * p.h_stride + (int64_t)(rb * RB) * p.l_stride;
+  const bf16_t* kb = p.k + (int64_t)b * p.b_stride + (int64_t)h * p.h_stride;
+
+  const int lrow = lane >> 2;
+  const int c_log = (lane & 3) ^ ((0x78 >> (((lrow >> 2) & 3) * 2)) & 3);
+  const int64_t lane_off = (int64_t)lrow * p.l_stride + c_log * 8;
+  auto stage = [&](int t_) {  // t_: step index inside this split
+    char* st = smem + (t_ % NSTG) * STAGE;
+    const bool live = t_ < p.nper;
+    const int64_t noff = (int64_t)(n0 + t_) * p.n_stride;
+#pragma unroll
+    for (int t = 0; t < PW; ++t) {
+      const int instr = t * 8 + wave;
+      if (live && instr < QI)
+        tied_glds16(qb + noff + (int64_t)(instr * 16) * p.l_stride + lane_off, st + instr * 1024);
+      else if (live)
+        tied_glds16(kb + noff + (int64_t)((instr - QI) * 16) * p.l_stride + lane_off, st + instr * 1024);
+      else
+        tied_glds16(g_tied_zero16, smem + DUMP);  // keeps every wave's DMA count per step at PW
+    }
+  };
+  if constexpr (SCALE) {
+    // w tile: rows rb*128 .. +127 of the MSA rows of this split (512 contiguous bytes each): one instruction = 2 MSA rows.
+    // The oldest operations of every wave: the counted wait of the first step covers them.
+    const float* wb = p.w + (int64_t)b * p.w_b + (int64_t)h * p.w_h + rb * RB + (lane & 31) * 4;
+    for (int i2 = wave; i2 * 2 < p.nper; i2 += 8)
+      tied_glds16(wb + (int64_t)(n0 + i2 * 2 + (lane >> 5)) * p.w_n, smem + W_OFF + i2 * 1024);
+  }
+
+  f32x4 acc[4][4];  // [key tile][query tile]
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) acc[kt][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int gq = (0x78 >> (((fr >> 2) & 3) * 2)) & 3;
+  const int q_rd = (wr * 64 + fr) * 64 + ((fq ^ gq) * 16);
+  const int k_rd = Q_BYTES + (wc * 64 + fr) * 64 + ((fq ^ gq) * 16);
+  const float* wrow = (const float*)(smem + W_OFF) + wr * 64 + fr;
+
+#pragma unroll
+  for (int s_ = 0; s_ < NSTG - 1; ++s_) stage(s_);
+  for (int t_ = 0; t_ < p.nper; ++t_) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW * (NSTG - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    stage(t_ + NSTG - 1);  // into the buffer of step t_ - 1, whose fragments every wave has consumed
+    const char* st = smem + (t_ % NSTG) * STAGE;
+    TFrag qf[4];
+    bf16x8 kf[4];
+    if (!(p.dbg & 2) || t_ == 0) {
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) qf[qt].v = *(const bf16x8*)(st + q_rd + qt * 1024);
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) kf[kt] = *(const bf16x8*)(st + k_rd + kt * 1024);
+    }
+    if constexpr (SCALE) {
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        const float ws = wrow[t_ * RB + qt * 16] * p.qscale;  // w[b,h,n, query row of this lane] * d_head^-0.5 (rf.py:252)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          qf[qt].u[e] = tpack2(__uint_as_float(qf[qt].u[e] << 16) * ws, __uint_as_float(qf[qt].u[e] & 0xffff0000u) * ws);
+      }
+    }
+    if (!(p.dbg & 4)) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+          // key tile as MFMA-A, query tile as MFMA-B: lane holds logits[i = 16 qt + fr][j = 16 kt + 4 fq .. +3]
+          acc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt].v, acc[kt][qt], 0, 0, 0);
+    }
+  }
+  if (p.dbg & 8) return;
+  // partial logits: 16-byte pieces, the four lanes of a row group cover 64 contiguous bytes, a wave's four key tiles 256
+  float* pr = p.part + (int64_t)sp * p.split_stride + (((int64_t)b * p.H + h) * L + rb * RB + wr * 64 + fr) * L + wc * 64 + 4 * fq;
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) *(f32x4*)(pr + (int64_t)(qt * 16) * L + kt * 16) = acc[kt][qt];
+}
+
+// att[row, :] = softmax(sum_s part[s][row, :]) for L = 256: one wave per row, 4 columns per lane
+__global__ __launch_bounds__(256) void tied_split_softmax_kernel(const float* part, int64_t split_stride, int nsplit,
+                                                                 bf16_t* att, int64_t rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f32x4 v = *(const f32x4*)(part + row * 256 + lane * 4);
+  for (int s_ = 1; s_ < nsplit; ++s_) v += *(const f32x4*)(part + (int64_t)s_ * split_stride + row * 256 + lane * 4);
+  float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+  mx = wave_max(mx);
+  float sm = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[e] = __expf(v[e] - mx);
+    sm += v[e];
+  }
+  sm = wave_sum(sm);
+  const float inv = 1.f / sm;
+  uint2 o;
+  o.x = tpack2(v[0] * inv, v[1] * inv);
+  o.y = tpack2(v[2] * inv, v[3] * inv);
+  *(uint2*)(att + row * 256 + lane * 4) = o;
+}
+
 __global__ __launch_bounds__(256) void tied_att_sym_kernel(const bf16_t* att, float* sym, int64_t sym_ld, int B, int H, int L) {
   // sym[b,i,j,h] = 0.5*(att[b,h,i,j] + att[b,h,j,i])
   const int64_t n = (int64_t)B * L * L * H;
@@ -190,6 +346,11 @@ __global__ __launch_bounds__(256) void tied_att_sym_kernel(const bf16_t* att, fl
   }
 }
 
+static int tied_dbg() {
+  static const int v = getenv("RF_TIED_DBG") ? atoi(getenv("RF_TIED_DBG")) : 0;
+  return v;
+}
+
 template <int L, bool SCALE>
 static int launch_tied(const TiedP& p, hipStream_t s) {
   constexpr int NSTG = L >= 256 ? 6 : 8;
@@ -198,6 +359,36 @@ static int launch_tied(const TiedP& p, hipStream_t s) {
   auto k = tied_logits_kernel<L, SCALE>;
   if (const int e = rf_enable_big_lds<tied_logits_kernel<L, SCALE>>()) return e;
   hipLaunchKernelGGL(k, dim3((unsigned)(p.B * p.H * (L / 64))), dim3(256), lds, s, p);
+  return rf_launch_status();
+}
+
+// contraction-split path: L == 256, N splits into nsplit ranges of <= 64 rows, workspace of nsplit * B*H*L*L floats
+static int tied_logits_split(const TiedP& p0, int L, float* ws, int64_t ws_elems, hipStream_t s) {
+  static const bool off = rf_env_flag("RF_NO_TIED_SPLIT");
+  if (off || !ws || L != 256 || p0.N % 2) return 1;  // 1 = not applicable: the caller falls back to the one-pass kernel
+  int nsplit = 2;
+  while (p0.N / nsplit > 64 && p0.N % (nsplit * 2) == 0) nsplit *= 2;
+  const int nper = p0.N / nsplit;
+  const int64_t one = (int64_t)p0.B * p0.H * L * L;
+  if (nper > 64 || nper < 4 || (nper & 1) || ws_elems < one * nsplit || ((uintptr_t)ws % 16)) return 1;
+  TiedSplitP p;
+  p.q = p0.q; p.k = p0.k;
+  p.b_stride = p0.b_stride; p.n_stride = p0.n_stride; p.h_stride = p0.h_stride; p.l_stride = p0.l_stride;
+  p.w = p0.w; p.w_b = p0.w_b; p.w_h = p0.w_h; p.w_n = p0.w_n; p.qscale = p0.qscale;
+  p.part = ws; p.split_stride = one;
+  p.B = p0.B; p.H = p0.H; p.N = p0.N; p.nsplit = nsplit; p.nper = nper;
+  p.dbg = p0.dbg;
+  const size_t lds = (size_t)TIED_SPLIT_NSTG * (128 * 64 + 256 * 64) + 1024 + (p.w ? (size_t)nper * 512 : 0);
+  const unsigned grid = (unsigned)(p.B * p.H * 2 * nsplit);
+  if (p.w) {
+    if (const int e = rf_enable_big_lds<tied_logits_split_kernel<true>>()) return e;
+    hipLaunchKernelGGL(tied_logits_split_kernel<true>, dim3(grid), dim3(512), lds, s, p);
+  } else {
+    if (const int e = rf_enable_big_lds<tied_logits_split_kernel<false>>()) return e;
+    hipLaunchKernelGGL(tied_logits_split_kernel<false>, dim3(grid), dim3(512), lds, s, p);
+  }
+  const int64_t rows = (int64_t)p.B * p.H * L;
+  hipLaunchKernelGGL(tied_split_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ws, one, nsplit, p0.att, rows);
   return rf_launch_status();
 }
 
@@ -232,6 +423,7 @@ extern "C" int rf_tied_logits_softmax(const void* q, const void* k, int64_t b_st
   p.b_stride = b_stride; p.n_stride = n_stride; p.l_stride = l_stride; p.h_stride = d_head;
   p.w = nullptr; p.w_b = p.w_h = p.w_n = 0; p.qscale = 1.f;
   p.att = (bf16_t*)att; p.B = B; p.H = H; p.N = N;
+  p.dbg = tied_dbg();
   hipStream_t s = (hipStream_t)stream;
   const int rc = tied_logits_dispatch(p, L, s);
   if (rc != 0 || !att_sym) return rc;
@@ -424,7 +616,7 @@ extern "C" int rf_tied_av(const void* att, const void* v, const int64_t v_stride
 extern "C" int rf_tied_attention(const void* q, const void* k, const void* v, const int64_t qk_strides[4],
                                  const int64_t v_strides[4], const float* w, const int64_t w_strides[3], float qscale,
                                  void* att, float* att_sym, int64_t sym_ld, void* out, const int64_t o_strides[4], int B,
-                                 int H, int N, int L, int d_head, void* stream) {
+                                 int H, int N, int L, int d_head, float* partial_ws, int64_t partial_ws_elems, void* stream) {
   if (!q || !k || !v || !att || !out || B <= 0 || H <= 0 || N <= 0) return RF_EINVAL;
   if (d_head != 32 || (L != 64 && L != 128 && L != 192 && L != 256)) return RF_EINVAL;
   if (((uintptr_t)q % 16) || ((uintptr_t)k % 16) || ((uintptr_t)att % 16)) return RF_EALIGN;
@@ -439,8 +631,10 @@ extern "C" int rf_tied_attention(const void* q, const void* k, const void* v, co
   p.w_b = w ? w_strides[0] : 0; p.w_h = w ? w_strides[1] : 0; p.w_n = w ? w_strides[2] : 0;
   p.qscale = qscale;
   p.att = (bf16_t*)att; p.B = B; p.H = H; p.N = N;
+  p.dbg = tied_dbg();
   hipStream_t s = (hipStream_t)stream;
-  int rc = tied_logits_dispatch(p, L, s);
+  int rc = tied_logits_split(p, L, partial_ws, partial_ws_elems, s);
+  if (rc == 1) rc = tied_logits_dispatch(p, L, s);
   if (rc != 0) return rc;
   if (att_sym && (rc = tied_sym(att, att_sym, sym_ld, B, H, L, s)) != 0) return rc;
   return rf_tied_av(att, v, v_strides, out, o_strides, B, H, N, L, d_head, stream);

@@ -172,12 +172,17 @@ def _hstrides(t):
     return I64x4(t.stride(0), t.stride(1), t.stride(2), t.stride(3))
 
 
-def tied_attention(q, k, v, out, att, w=None, qscale=1.0, att_sym=None):
+def tied_attention(q, k, v, out, att, w=None, qscale=1.0, att_sym=None, partial_ws=None):
     """Tied MSA-row attention core (csrc/tied.hip).  q, k, v, out: bf16 views indexed [B, N, H, L, 32] (any strides with
     a contiguous head slice); att: bf16 [B, H, L, L] (workspace + result); w: fp32 [B, H, N, L] position weights folded
-    into the logits kernel (None: q already carries them); att_sym: fp32 [B, L, L, H] or None."""
+    into the logits kernel (None: q already carries them); att_sym: fp32 [B, L, L, H] or None.  partial_ws: fp32 workspace
+    for the contraction-split logits (L == 256); allocated here when None, pass False to force the one-pass kernel."""
     B, N, H, L_, dh = q.shape
-    _need_cuda(q, k, v, out, att, w, att_sym)
+    if partial_ws is None and L_ == 256 and N % 2 == 0:
+        partial_ws = torch.empty((4 if N > 128 else 2) * B * H * L_ * L_, device=q.device, dtype=F32)
+    if partial_ws is False:
+        partial_ws = None
+    _need_cuda(q, k, v, out, att, w, att_sym, partial_ws)
     if q.stride() != k.stride():
         raise ValueError("q and k must share their strides")
     ws = I64x3(w.stride(0), w.stride(1), w.stride(2)) if w is not None else I64x3(0, 0, 0)
@@ -185,7 +190,8 @@ def tied_attention(q, k, v, out, att, w=None, qscale=1.0, att_sym=None):
         raise ValueError("w must be [B, H, N, L] with contiguous L")
     check(lib.rf_tied_attention(ptr(q), ptr(k), ptr(v), C.byref(_hstrides(q)), C.byref(_hstrides(v)), ptr(w), C.byref(ws),
                                 float(qscale), ptr(att), ptr(att_sym), att_sym.shape[-1] if att_sym is not None else 0,
-                                ptr(out), C.byref(_hstrides(out)), B, H, N, L_, dh, stream()), "rf_tied_attention")
+                                ptr(out), C.byref(_hstrides(out)), B, H, N, L_, dh, ptr(partial_ws),
+                                partial_ws.numel() if partial_ws is not None else 0, stream()), "rf_tied_attention")
     return out
 
 

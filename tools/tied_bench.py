@@ -28,6 +28,8 @@ print(f"v2 core (logits+softmax with weights, A.V): {t_all*1e3:.1f} us = {2*fl/t
 vs, os_ = I64x4(*v.stride()[:4]), I64x4(*o5.stride()[:4])
 t_av = timeit(lambda: lib.rf_tied_av(ops.ptr(att), ops.ptr(v), C.byref(vs), ops.ptr(out), C.byref(os_), B, H, N, L, dh, ops.stream()))
 print(f"   A.V kernel alone: {t_av*1e3:.1f} us = {fl/t_av/1e9:.0f} TF/s; logits+softmax: {(t_all-t_av)*1e3:.1f} us = {fl/(t_all-t_av)/1e9:.0f} TF/s")
+t_one = timeit(lambda: ops.tied_attention(q, k, v, o5, att, w=w, qscale=0.17, partial_ws=False))
+print(f"   one-pass logits kernel instead of the contraction-split one: {t_one*1e3:.1f} us -> logits+softmax {(t_one-t_av)*1e3:.1f} us")
 t_nw = timeit(lambda: ops.tied_attention(q, k, v, o5, att, w=None))
 print(f"   without position weights (q pre-scaled): {t_nw*1e3:.1f} us -> logits+softmax {(t_nw-t_av)*1e3:.1f} us")
 t_sym = timeit(lambda: ops.tied_attention(q, k, v, o5, att, w=w, qscale=0.17, att_sym=sym))
