@@ -17,6 +17,10 @@ def family(name):
         return "gemm_fast_kernel"
     if "gemm_wreg_kernel" in name:
         return "gemm_wreg_kernel"
+    if "tied_logits_split_kernel" in name:
+        return "tied_logits_split_kernel"
+    if "tied_split_softmax_kernel" in name:
+        return "tied_split_softmax_kernel"
     if "tied_logits_kernel" in name:
         return "tied_logits_kernel"
     if "tied_av_kernel" in name:
