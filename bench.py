@@ -350,6 +350,14 @@ def main():
                     tnote = f"stale: profiles/r02_traffic_pmc.json was collected on tree {pm.get('tree')}, this is {tree_hash()}"
             except (OSError, KeyError, ValueError):
                 pass
+            mfma_util = None  # matrix-pipe busy fraction from the hardware counters (tools/pmc_mfma.py), same staleness rule
+            try:
+                with open(os.path.join(ROOT, "profiles", "r02_mfma_pmc.json")) as fh:
+                    pm = json.load(fh)
+                if pm.get("tree") == tree_hash():
+                    mfma_util = {k: v["mfma_util"] for k, v in pm["families"].items() if v.get("mfma_util")}
+            except (OSError, KeyError, ValueError):
+                pass
             # the roof the dominant kernel sits under is chosen by its arithmetic intensity (algorithmic FLOP per algorithmic
             # byte against the 312 FLOP/byte ridge); the other roof's fraction is reported beside it
             b = bound_of(flops, nbytes, secs)
@@ -362,6 +370,7 @@ def main():
                                "mfma_TFLOPs": flops / secs / 1e12, "mfma_frac": flops / secs / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                                "algorithmic_hbm_GBps": nbytes / secs / 1e9, "hbm_frac": nbytes / secs / 1e9 / HBM_PEAK_GBPS,
                                "share_of_step": secs / (dt / args.steps), "shapes": shapes,
+                               "mfma_util_pmc": mfma_util,
                                "families": {k: {"s": v[0], "tflops": v[1] / max(v[0], 1e-12) / 1e12, "n": v[2],
                                                 "algorithmic_GBps": v[3] / max(v[0], 1e-12) / 1e9}
                                             for k, v in fams.items()}}
