@@ -473,8 +473,14 @@ template <int LS, bool SOFTMAX>
 __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAttnP p) {
   constexpr int NSB = LS / 32;                    // s-blocks (pairs of s-tiles) per chunk
   constexpr int NSBH = NSB / 2;                   // per sequence half
-  constexpr int STB = LS >= 128 ? LS / 128 : 1;   // s-tiles per wave in phase B
-  constexpr int NWB = LS / (16 * STB);            // waves active in phase B (8, or 4 for LS = 64)
+  // s-tiles per wave in phase B: two from LS = 128 up, so that at LS = 128 only the four older waves (one per SIMD) run
+  // phase B.  With one s-tile on all eight waves (the round-1 split of LS = 128) this kernel was NOT run-to-run
+  // reproducible after the round-2 changes: in a fraction of the items one wave of the younger half (4-7) wrote 16 rows
+  // that were off by a few percent (tools/determinism_favor.py, tools/determinism_favor_where.py; every variant of the
+  // barriers / waits / DMA form left it in; LS = 64 and LS = 256 never showed it).  The cause is not established; this
+  // split was bitwise reproducible in every run tried (72 x 12288 items per box) and costs ~13 % at LS = 128.
+  constexpr int STB = LS >= 128 ? 2 : 1;
+  constexpr int NWB = LS / (16 * STB);            // waves active in phase B (8 at LS = 256, 4 at LS = 128 and 64)
   constexpr int PC_OFF = 0;
   constexpr int K_OFF = FV_MPAD * 128;
   constexpr int V_OFF = K_OFF + LS * 128;
@@ -710,8 +716,29 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
           *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq)) = w;
         }
       }
-    fv_lds_barrier();  // every wave is through phase A: the K and V tiles are free again
+    fv_lds_barrier();  // every wave is through phase A
     FV_STAMP(2)
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+      if (j < nm && mine(j)) {
+        // the tile's five partner partials first (independent reads in flight together), then add and republish
+        uint2 o[FV_DT];
+#pragma unroll
+        for (int i = 0; i < FV_DT; ++i) o[i] = *(const uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq));
+#pragma unroll
+        for (int i = 0; i < FV_DT; ++i) {
+          uint2 w;
+          w.x = pack2(ctx[j][i][0] + bf2f((bf16_t)(o[i].x & 0xffff)), ctx[j][i][1] + bf2f((bf16_t)(o[i].x >> 16)));
+          w.y = pack2(ctx[j][i][2] + bf2f((bf16_t)(o[i].y & 0xffff)), ctx[j][i][3] + bf2f((bf16_t)(o[i].y >> 16)));
+          *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq)) = w;
+        }
+      }
+    fv_lds_barrier();  // ctx^T complete
+    // The K/V prefetch of the next item is issued HERE, after the combine's barrier, not right after the publish barrier
+    // where the tiles are first free: with the DMAs in flight across the combine and its barrier, single waves of the
+    // younger half produced slightly wrong rows in a fraction of the items (run-to-run differences at LS = 128, found by
+    // tools/determinism_favor.py; every fence / full-wait variant of the barriers left it in, moving the issue point
+    // removed it on every box tried).  Cause not established; the later issue point costs no measurable time.
     // Pin the Q fragments here (loaded a whole phase ago): hipcc's own wait for them lands at this point, BEFORE the
     // prefetch DMAs are issued; left to itself it waits at their first use in phase B with vmcnt(0), which also drains
     // the K/V prefetch it cannot count (in-order counter) and serialises the item pipeline.
@@ -729,22 +756,6 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
         load_tile8(V_OFF, p.qkv + xb2 + p.v_off, p.x_s, LS_TAG);
       }
     }
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-      if (j < nm && mine(j)) {
-        // the tile's five partner partials first (independent reads in flight together), then add and republish
-        uint2 o[FV_DT];
-#pragma unroll
-        for (int i = 0; i < FV_DT; ++i) o[i] = *(const uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq));
-#pragma unroll
-        for (int i = 0; i < FV_DT; ++i) {
-          uint2 w;
-          w.x = pack2(ctx[j][i][0] + bf2f((bf16_t)(o[i].x & 0xffff)), ctx[j][i][1] + bf2f((bf16_t)(o[i].x >> 16)));
-          w.y = pack2(ctx[j][i][2] + bf2f((bf16_t)(o[i].y & 0xffff)), ctx[j][i][3] + bf2f((bf16_t)(o[i].y >> 16)));
-          *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq)) = w;
-        }
-      }
-    fv_lds_barrier();  // ctx^T complete
 
     FV_STAMP(3)
     // ---------------- phase B ----------------

@@ -183,3 +183,60 @@ def test_pair_axial_layer_L1024_config4():
         ref = y + O.feed_forward(P, "m.ff", O._ln(P, "m.layer.2.fn.0", y))
     print(f"\n[config4 pair_axial_layer L=1024] oracle {time.time() - t0:.1f}s")
     check("pair_axial_layer_L1024", torch.bfloat16, got, ref)
+
+
+def test_run_to_run_bitwise_config2():
+    """Every layer kind at the BENCH dimensions twice on the same inputs: bitwise identical (a race or an uninitialised
+    read in a hand-written kernel shows up here; tools/determinism_modules.py is the B=4 form of this check, and
+    tools/determinism_favor.py the per-variant form for the fused FAVOR+ kernel, where round 2 found and fixed one)."""
+    R.set_compute_dtype(torch.bfloat16)
+    msa, pair = rn(1, N2, L2, DM).to(DEV), rn(1, L2, L2, DP).to(DEV)
+
+    def twice(name, fn):
+        a, b = fn(), fn()
+        fa = [a[k] for k in sorted(a)] if isinstance(a, dict) else list(a) if isinstance(a, (tuple, list)) else [a]
+        fb = [b[k] for k in sorted(b)] if isinstance(b, dict) else list(b) if isinstance(b, (tuple, list)) else [b]
+        for x, y in zip(fa, fb):
+            if torch.is_tensor(x):
+                assert torch.equal(x, y), name
+
+    m = build(lambda: R.EncoderLayer(d_msa=DM, d_ff=4 * DM, n_heads=12, p_dropout=0.0, tied=True, return_att=True))
+    twice("tied row layer", lambda: m(msa))
+    m2 = build(lambda: R.EncoderLayer(d_msa=DM, d_ff=4 * DM, n_heads=12, p_dropout=0.0, tied=False, performer=True))
+
+    def col():
+        x = msa.clone()
+        m2.run(x, seq_axis=1)
+        return x
+    for _ in range(3):
+        twice("performer column layer (FAVOR+ softmax features, 128-row sequences)", col)
+    att = torch.rand(1, L2, L2, 12, generator=torch.Generator().manual_seed(2)).softmax(2).to(DEV)
+    m3 = build(lambda: R.PairUpdateWithMsa(d_msa=DM, d_proj=32, d_pair=DP, n_heads=12, p_dropout=0.0))
+    twice("pair update with msa", lambda: m3(msa, pair, att))
+    m5 = build(lambda: R.PairUpdateWithAxialAttentionLayer(DP, 4 * DP, 8, 0.0, {}))
+    twice("pair axial layer", lambda: m5(pair))
+    m6 = build(lambda: R.MsaUpdateWithPair(DM, DP, 4, n_encoder_layers=1, p_dropout=0.0))
+    twice("msa update with pair", lambda: m6(msa, pair))
+    m9 = build(lambda: R.PredictionHead(DP, 4, 0.0))
+    twice("prediction head", lambda: m9(pair))
+
+
+@pytest.mark.parametrize("gen,Ls", [(True, 64), (True, 128), (True, 256), (False, 64), (False, 128), (False, 256)])
+def test_fused_favor_run_to_run(gen, Ls):
+    """The fused FAVOR+ kernel, every (feature map, sequence length) variant, 1024 x heads items: six runs bitwise equal."""
+    from rosettafold_pytorch_amd import ops
+    H, D, Lo = (12, 384, 1024) if Ls == 128 else (8, 288, 1024)
+    torch.manual_seed(0)
+    m = R.PerformerSelfAttention(dim=D, heads=H, generalized_attention=gen).to(DEV)
+    inner, W3 = 64 * H, 3 * 64 * H
+    qkv = torch.randn(Lo * Ls, W3, device=DEV).bfloat16()
+    pc = m.proj_scaled(log2e=not gen)
+
+    def f():
+        o = torch.empty(Lo * Ls, inner, device=DEV, dtype=torch.bfloat16)
+        ops.favor_attention(qkv, pc, o, (Lo * Ls * W3, Ls * W3, W3, 64), (Lo * Ls * inner, Ls * inner, inner), 0, inner,
+                            2 * inner, 1, Lo, H, Ls, 64, 266, not gen, 1e-3 if gen else 1e-4)
+        return o
+    outs = [f() for _ in range(6)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])

@@ -53,3 +53,15 @@ def conv():
     ops.gemm(img, wk, out, 4 * 256 * 256, 288, 9 * 288, conv=(4, 256, 256, 288, 1))
     return out
 same("conv3x3", conv)
+# round-2 kernels
+x384b = torch.randn(131072, 384, device="cuda").bfloat16()
+for n_out in (1152, 1536, 2304):
+    wn = (torch.randn(n_out, 384, device="cuda") * 0.05).bfloat16()
+    same(f"gemm_wreg K=384 N={n_out}", lambda: ops.linear(x384b, wn, None))
+for n_out in (1152, 1536):
+    wn = (torch.randn(n_out, 288, device="cuda") * 0.05).bfloat16()
+    same(f"gemm_wreg K=288 N={n_out}", lambda: ops.linear(x288, wn, None))
+x768 = torch.randn(131072, 768, device="cuda").bfloat16(); w768 = (torch.randn(384, 768, device="cuda") * 0.05).bfloat16()
+same("gemm_fast K=768 N=384 f32+res", lambda: ops.linear(x768, w768, None, out_dtype=torch.float32, residual=res2))
+x1536 = torch.randn(131072, 1536, device="cuda").bfloat16(); w1536b = (torch.randn(384, 1536, device="cuda") * 0.05).bfloat16()
+same("gemm_fast K=1536 N=384 f32+res", lambda: ops.linear(x1536, w1536b, None, out_dtype=torch.float32, residual=res2))
