@@ -504,10 +504,12 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
 
   // [nrows][64] bf16 tile -> swizzled LDS image; a wave's instruction covers 8 rows (row = 8*it + lane/8, rows & 7 == lane/8)
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const int dma_row = lane >> 3;
-  const int dma_col = ((lane & 7) ^ dma_row) * 8;
   auto load_tile8 = [&](int lds_off, const bf16_t* gp, int64_t stride, auto nrows_tag) {
     constexpr int NI = decltype(nrows_tag)::value * 8 / 64;
+    int ln = lane;  // opaque: the per-lane source offsets are rebuilt at every call instead of living in (spilled) registers
+    asm volatile("" : "+v"(ln));
+    const int dma_row = ln >> 3;
+    const int dma_col = ((ln & 7) ^ dma_row) * 8;
     const bf16_t* g0 = gp + (int64_t)dma_row * stride + dma_col;
 #pragma unroll
     for (int k = 0; k < (NI + 7) / 8; ++k) {
@@ -556,13 +558,15 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
     FV_STAMP(0)
     bf16x8 qf[STB][2];
     auto load_q = [&](int chunk) {
+      int frq = fr, fqq = fq;  // opaque copies: keeps the row / chunk offsets out of the kernel-long live ranges
+      asm volatile("" : "+v"(frq), "+v"(fqq));
       if (wave < NWB) {
 #pragma unroll
         for (int t = 0; t < STB; ++t) {
-          const int s = chunk * LS + (wave * STB + t) * 16 + fr;
+          const int s = chunk * LS + (wave * STB + t) * 16 + frq;
           const bf16_t* qrow = p.qkv + xb + p.q_off + (int64_t)s * p.x_s;
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk) qf[t][kk] = *(const bf16x8*)(qrow + (kk * 4 + fq) * 8);
+          for (int kk = 0; kk < 2; ++kk) qf[t][kk] = *(const bf16x8*)(qrow + (kk * 4 + fqq) * 8);
         }
       }
     };
@@ -570,6 +574,8 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
 
     float gmax = 0.f;
     if constexpr (SOFTMAX) {
+      int frS = fr, fqS = fq;
+      asm volatile("" : "+v"(frS), "+v"(fqS));
       for (int s = tid; s < LS; s += 512) {
         float a = 0.f;
 #pragma unroll
@@ -591,14 +597,14 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk)
-            kf[t][kk] = *(const bf16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + fr, kk * 4 + fq));
+            kf[t][kk] = *(const bf16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + frS, kk * 4 + fqS));
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           if (j < nm) {
             bf16x8 pfj[2];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) pfj[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off((m0t + j) * 16 + fr, kk * 4 + fq));
-            const bool valid = (m0t + j) * 16 + fr < FV_M;
+            for (int kk = 0; kk < 2; ++kk) pfj[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off((m0t + j) * 16 + frS, kk * 4 + fqS));
+            const bool valid = (m0t + j) * 16 + frS < FV_M;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
               f32x4 a = {0.f, 0.f, 0.f, 0.f};
