@@ -5,8 +5,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rosettafold_pytorch_amd as R
 from rosettafold_pytorch_amd import ops
 torch.manual_seed(0)
-gen = True
-Ls, Lo, H, D = 128, 1024, 12, 384
+gen = os.environ.get("FV_GEN", "1") == "1"   # 1: ReLU features, 0: softmax features
+Ls = int(os.environ.get("FV_LS", "128"))
+Lo, H, D = 1024, (12 if Ls == 128 else 8), (384 if Ls == 128 else 288)
+NRUN = int(os.environ.get("FV_RUNS", "24"))
 m = R.PerformerSelfAttention(dim=D, heads=H, generalized_attention=gen).cuda()
 inner = 64 * H; W3 = 3 * inner
 qkv = torch.randn(Lo * Ls, W3, device="cuda").bfloat16()
@@ -15,7 +17,7 @@ def f():
     o = torch.empty(Lo * Ls, inner, device="cuda", dtype=torch.bfloat16)
     ops.favor_attention(qkv, pc, o, (Lo * Ls * W3, Ls * W3, W3, 64), (Lo * Ls * inner, Ls * inner, inner), 0, inner, 2 * inner, 1, Lo, H, Ls, 64, 266, not gen, 1e-3 if gen else 1e-4)
     return o
-outs = [f() for _ in range(24)]
+outs = [f() for _ in range(NRUN)]
 torch.cuda.synchronize()
 a = outs[0].view(Lo, Ls, H, 64)
 for k, o in enumerate(outs[1:]):
