@@ -11,11 +11,12 @@ the gather of the results to rank 0 (RCCL), inside the timed region.  Rank 0 pri
 at N=1:
   * roofline: the dominant kernel family timed live with HIP events around every rf_gemm launch of one extra profiled
     step (the library reports which kernel family each launch took: rf_gemm_last_family); achieved = algorithmic FLOPs of
-    those launches / their time.  `traffic` comes from the PMC file of THIS tree (profiles/r02_traffic_pmc.json carries a
+    those launches / their time.  `traffic` comes from the PMC file of THIS tree (profiles/r03_traffic_pmc.json carries a
     hash of csrc/); a file collected on another tree is reported as stale and `traffic` stays null.
-  * parity: one forward of the SAME inputs in the exact-fp32 mode (the mode that carries the strict oracle parity,
-    tests/test_config2_gpu.py) -> agreement of the timed bf16 path with it: distogram argmax agreement, relative L2 of the
-    four logit maps / xyz / plddt, and the fp32-mode step time.
+  * parity: the SAME inputs in every compute mode of the library -- the timed bf16 path, the fp16-operand build of the
+    same kernels (librfmi_f16.so) and the exact-fp32 mode (pinned to the CPU oracle at depth, tests/test_depth_gpu.py) --
+    each with its step time; agreement with the fp32 mode: distogram argmax (all pairs / clear-margin pairs), relative L2
+    of the four logit maps / xyz / plddt.
   * cpu_baseline: the CPU oracle (oracle/rf_oracle.py, pinned to the reference's golden vectors) on the host cores: one
     layer of each kind at the bench shapes (B=1), warm-up + best of 3, scaled by the layer counts.
 Other workloads: --config 4 (BASELINE.json configs[3]: B=1, N=64, L=1024) and --config 5 (configs[4]: the SE(3) structure
@@ -145,31 +146,48 @@ def rel_l2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
-def parity_block(model, inputs, out_bf16, R, steps=2):
-    """The timed bf16 path against the exact-fp32 mode of the same library on the same inputs and weights."""
-    R.set_compute_dtype(torch.float32)
-    try:
-        lg, xyz, pl = model(*inputs)  # warm-up (weight copies of this mode)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            lg, xyz, pl = model(*inputs)
-        torch.cuda.synchronize()
-        ms32 = 1e3 * (time.perf_counter() - t0) / steps
-    finally:
-        R.set_compute_dtype(torch.bfloat16)
-    lb, xb, pb = out_bf16
+def _agreement(lb, xb, pb, lg, xyz, pl):
     agree = {k: (lb[k].argmax(-1) == lg[k].argmax(-1)).float().mean().item() for k in lg}
     # margin-aware view: bins whose top-2 fp32 logits are further apart than 2 % of the map's range cannot flip by rounding
     d = lg["dist"]
     top2 = d.topk(2, -1).values
     clear = (top2[..., 0] - top2[..., 1]) > 0.02 * (d.max() - d.min())
     agree_clear = (lb["dist"].argmax(-1) == d.argmax(-1))[clear].float().mean().item() if clear.any() else None
-    return {"reference_mode": "exact fp32 kernels of the same library (the mode the oracle tests pin: tests/test_config2_gpu.py)",
-            "dist_argmax_agreement": agree["dist"], "argmax_agreement": agree,
+    return {"dist_argmax_agreement": agree["dist"], "argmax_agreement": agree,
             "dist_argmax_agreement_clear_margin": agree_clear, "clear_margin_fraction": clear.float().mean().item(),
-            "rel_l2": {**{k: rel_l2(lb[k], lg[k]) for k in lg}, "xyz": rel_l2(xb, xyz), "plddt": rel_l2(pb, pl)},
-            "fp32_mode_ms_per_step": ms32}
+            "rel_l2": {**{k: rel_l2(lb[k], lg[k]) for k in lg}, "xyz": rel_l2(xb, xyz), "plddt": rel_l2(pb, pl)}}
+
+
+def _time_mode(model, inputs, R, dtype, steps):
+    R.set_compute_dtype(dtype)
+    try:
+        out = model(*inputs)  # warm-up (weight copies of this mode)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = model(*inputs)
+        torch.cuda.synchronize()
+        return out, 1e3 * (time.perf_counter() - t0) / steps
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+
+
+def parity_block(model, inputs, out_bf16, R, ms_bf16, steps=2):
+    """Every compute mode of the library on the SAME inputs and weights, against the exact-fp32 mode (the mode that
+    tests/test_depth_gpu.py and tests/test_config2_gpu.py pin to the CPU oracle at 5e-4 / 2e-5): the timed bf16 path, and
+    the fp16-operand build of the same kernels (librfmi_f16.so: same MFMA rate and bytes, 8x smaller operand rounding),
+    each with its own step time.  Top-level fields describe the timed (bf16) path."""
+    (lg, xyz, pl), ms32 = _time_mode(model, inputs, R, torch.float32, steps)
+    (l16, x16, p16), ms16 = _time_mode(model, inputs, R, torch.float16, max(steps, 3))
+    lb, xb, pb = out_bf16
+    bf = _agreement(lb, xb, pb, lg, xyz, pl)
+    fp = _agreement(l16, x16, p16, lg, xyz, pl)
+    return {"reference_mode": "exact fp32 kernels of the same library (pinned to the CPU oracle at depth: tests/test_depth_gpu.py)",
+            **bf, "fp32_mode_ms_per_step": ms32,
+            "modes": {"bf16": {**bf, "ms_per_step": ms_bf16, "library": "librfmi.so (v_mfma_f32_16x16x32_bf16)"},
+                      "fp16": {**fp, "ms_per_step": ms16, "vs_bf16_step_time": ms16 / ms_bf16,
+                               "library": "librfmi_f16.so (v_mfma_f32_16x16x32_f16)"},
+                      "fp32": {"ms_per_step": ms32, "library": "librfmi.so (v_mfma_f32_16x16x4_f32)"}}}
 
 
 def cpu_baseline(cfg):
@@ -252,7 +270,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -272,7 +290,7 @@ def main():
 
     import rosettafold_pytorch_amd as R
     cfg = CONFIGS[args.config]
-    R.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    R.set_compute_dtype({"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype])
     torch.manual_seed(1234)  # identical weights on every rank
     B, N, L = cfg["B"], cfg["N"], cfg["L"]
     if args.config == 5:
@@ -341,18 +359,18 @@ def main():
             name, (secs, flops, n, nbytes) = max(fams.items(), key=lambda kv: kv[1][0])
             traffic, tnote = None, "no PMC collection for this tree (tools/pmc_traffic.py)"
             try:
-                with open(os.path.join(ROOT, "profiles", "r02_traffic_pmc.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r03_traffic_pmc.json")) as fh:
                     pm = json.load(fh)
                 if pm.get("tree") == tree_hash():
                     traffic = pm["families"][name.split(" ")[0]]["hbm_bytes_per_launch"]
                     tnote = f"rocprofv3 PMC passes (FETCH_SIZE x2, WRITE_SIZE) on this tree ({pm['tree']})"
                 else:
-                    tnote = f"stale: profiles/r02_traffic_pmc.json was collected on tree {pm.get('tree')}, this is {tree_hash()}"
+                    tnote = f"stale: profiles/r03_traffic_pmc.json was collected on tree {pm.get('tree')}, this is {tree_hash()}"
             except (OSError, KeyError, ValueError):
                 pass
             mfma_util = None  # matrix-pipe busy fraction from the hardware counters (tools/pmc_mfma.py), same staleness rule
             try:
-                with open(os.path.join(ROOT, "profiles", "r02_mfma_pmc.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", "r03_mfma_pmc.json")) as fh:
                     pm = json.load(fh)
                 if pm.get("tree") == tree_hash():
                     mfma_util = {k: v["mfma_util"] for k, v in pm["families"].items() if v.get("mfma_util")}
@@ -375,7 +393,7 @@ def main():
                                                 "algorithmic_GBps": v[3] / max(v[0], 1e-12) / 1e9}
                                             for k, v in fams.items()}}
         if world == 1 and full and not args.no_parity:
-            res["parity"] = parity_block(model, inputs, out, R)
+            res["parity"] = parity_block(model, inputs, out, R, 1e3 * dt / args.steps)
         if world == 1 and full and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)

@@ -12,7 +12,13 @@
  *     never synchronise, keep no global state: re-entrant;
  *   - return value: 0 = launched; >0 = hipError_t from the launch; <0 = argument rejected
  *     (RF_EINVAL...) and nothing was launched;
- *   - dtype codes: RF_F32 = 0, RF_BF16 = 1.  "T" below = activation dtype chosen by the caller.
+ *   - dtype codes: RF_F32 = 0, RF_BF16 = 1, RF_F16 = 2.  "T" below = activation dtype chosen by the caller.
+ *   - the kernel sources are built twice: librfmi.so computes its 16-bit MFMA contractions in bfloat16
+ *     (v_mfma_f32_16x16x32_bf16) and accepts {RF_F32, RF_BF16}; librfmi_f16.so computes them in IEEE fp16
+ *     (v_mfma_f32_16x16x32_f16: same rate and bytes, 11 significand bits instead of 8, range 65504) and accepts
+ *     {RF_F32, RF_F16}.  Both export exactly the symbols declared here; rf_h16_dtype() says which 16-bit code a
+ *     loaded library takes, every other 16-bit code is rejected with RF_EINVAL.  Wherever a comment below says
+ *     "bf16" for an operand it means "the library's 16-bit type".
  */
 #ifndef RFMI_H
 #define RFMI_H
@@ -24,6 +30,7 @@ extern "C" {
 
 #define RF_F32 0
 #define RF_BF16 1
+#define RF_F16 2
 
 #define RF_EINVAL (-1)   /* inconsistent sizes / unsupported combination */
 #define RF_EALIGN (-2)   /* pointer or stride not aligned as the kernel needs */
@@ -344,6 +351,7 @@ int rf_debug_gemm_fast_stamps(void* buf);
 
 int rf_version(void);
 const char* rf_build_info(void);
+int rf_h16_dtype(void); /* RF_BF16 (librfmi.so) or RF_F16 (librfmi_f16.so) */
 
 #ifdef __cplusplus
 }

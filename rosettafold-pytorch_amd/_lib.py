@@ -1,4 +1,4 @@
-"""ctypes binding of librfmi.so (include/rfmi.h).  The product has NO fallback: if the HIP
+"""ctypes binding of librfmi.so / librfmi_f16.so (include/rfmi.h).  The product has NO fallback: if a HIP
 library is missing or a symbol is absent this module raises at import."""
 import ctypes as C
 import os
@@ -8,7 +8,7 @@ import torch  # noqa: F401  -- must be loaded first: librfmi.so binds to the HIP
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librfmi.so")
 
-RF_F32, RF_BF16 = 0, 1
+RF_F32, RF_BF16, RF_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_RELU_EPS, ACT_LEAKY, ACT_BLOCK_LN32 = 0, 1, 2, 3, 4, 5
 BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 AMODE_PLAIN, AMODE_CONV3X3 = 0, 1
@@ -86,21 +86,60 @@ PROTOTYPES = {
     "rf_debug_gemm_fast_stamps": [vp],
     "rf_gemm_last_family": [],
     "rf_version": [],
+    "rf_h16_dtype": [],
 }
 
-if not os.path.exists(LIB_PATH):
-    raise ImportError(
-        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-        "(or `make -C rosettafold-pytorch_amd/csrc`).  There is no CPU / PyTorch fallback.")
+def _load(path):
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C rosettafold-pytorch_amd/csrc`).  There is no CPU / PyTorch fallback.")
+    handle = C.CDLL(path)  # RTLD_LOCAL: the two builds export the same symbol names and never see each other
+    for _name, _args in PROTOTYPES.items():
+        _fn = getattr(handle, _name)  # AttributeError if the library does not export it
+        _fn.argtypes = _args
+        _fn.restype = C.c_int
+    handle.rf_instnorm_ws_bytes.restype = C.c_int64
+    handle.rf_build_info.restype = C.c_char_p
+    handle.rf_build_info.argtypes = []
+    return handle
 
-lib = C.CDLL(LIB_PATH)
-for _name, _args in PROTOTYPES.items():
-    _fn = getattr(lib, _name)  # AttributeError if the library does not export it
-    _fn.argtypes = _args
-    _fn.restype = C.c_int
-lib.rf_instnorm_ws_bytes.restype = C.c_int64
-lib.rf_build_info.restype = C.c_char_p
-lib.rf_build_info.argtypes = []
+
+LIB16_PATH = os.path.join(_HERE, "librfmi_f16.so")
+# librfmi.so: 16-bit MFMA operand type bfloat16 (accepts RF_F32 / RF_BF16); librfmi_f16.so: the same sources built with
+# IEEE fp16 as the 16-bit type (accepts RF_F32 / RF_F16).  Both are required: a missing library is an import error.
+LIBS = {RF_BF16: _load(LIB_PATH), RF_F16: _load(LIB16_PATH)}
+for _code, _h in LIBS.items():
+    if _h.rf_h16_dtype() != _code:
+        raise ImportError(f"{_h.rf_build_info().decode()} reports 16-bit dtype code {_h.rf_h16_dtype()}, expected {_code}")
+
+
+class _ActiveLibrary:
+    """`lib.rf_xxx(...)` goes to the library selected by select_h16() (model.set_compute_dtype): the bfloat16 build by
+    default.  Attribute writes (bench.py wraps rf_gemm to time it) land on the selected library too."""
+
+    def __init__(self):
+        object.__setattr__(self, "_code", RF_BF16)
+
+    def __getattr__(self, name):
+        return getattr(LIBS[object.__getattribute__(self, "_code")], name)
+
+    def __setattr__(self, name, value):
+        setattr(LIBS[object.__getattribute__(self, "_code")], name, value)
+
+
+lib = _ActiveLibrary()
+
+
+def select_h16(code):
+    """Route every following call to the build whose 16-bit type is `code` (RF_BF16 or RF_F16)."""
+    if code not in LIBS:
+        raise ValueError(f"no library for 16-bit dtype code {code}")
+    object.__setattr__(lib, "_code", code)
+
+
+def active_h16():
+    return object.__getattribute__(lib, "_code")
 
 
 class RfmiError(RuntimeError):

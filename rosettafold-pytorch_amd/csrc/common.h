@@ -6,37 +6,79 @@
 
 #include "rfmi.h"
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(4))) short bf16x4;
+// ---- the 16-bit MFMA operand type of this build ("h16") ---------------------------------------------------------------
+// The library is compiled twice from the same sources (csrc/Makefile):
+//   librfmi.so       h16 = bfloat16   (RF_H16 == RF_BF16):  v_mfma_f32_16x16x32_bf16, v_cvt_pk_bf16_f32
+//   librfmi_f16.so   h16 = IEEE half  (RF_H16 == RF_F16, -DRF_H16_IS_F16):  v_mfma_f32_16x16x32_f16, v_cvt_pk_f16_f32
+// Same MFMA rate, same bytes; fp16 carries 11 significand bits against bf16's 8, i.e. 8x smaller operand rounding (the
+// whole-model gap of the 16-bit path is operand rounding amplified by depth), at the price of fp16's
+// range (|x| < 65504): kernels whose 16-bit intermediates are sums over the sequence scale them in the f16 build (favor.hip).
+// fp32 accumulation, fp32 residual streams and fp32 statistics are the same in both builds.  Kernel code is written once
+// against h16_t / h2f / f2h / rf_pack2_h16 / rf_mfma16; a dtype code other than RF_F32 / RF_H16 is rejected by every entry
+// point of a build (RF_EINVAL), so a tensor of the other 16-bit type can never be misread.
+typedef __attribute__((ext_vector_type(8))) short h16x8;
+typedef __attribute__((ext_vector_type(4))) short h16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef unsigned short bf16_t;
+typedef unsigned short h16_t;
+typedef __attribute__((ext_vector_type(2))) float rf_f32x2;
 
 #define RF_WAVE 64
 
-__device__ __forceinline__ float bf2f(bf16_t u) { return __uint_as_float(((unsigned)u) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float x) {
+#ifdef RF_H16_IS_F16
+#define RF_H16 RF_F16
+#define RF_H16_ONE2 0x3C003C00u  // two packed 1.0
+typedef __attribute__((ext_vector_type(2))) _Float16 rf_h16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 rf_h16x8n;
+__device__ __forceinline__ float h2f(h16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+__device__ __forceinline__ h16_t f2h(float x) { return __builtin_bit_cast(h16_t, (_Float16)x); }  // round-to-nearest-even
+__device__ __forceinline__ f32x4 rf_mfma16(h16x8 a, h16x8 b, f32x4 c, int, int, int) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(rf_h16x8n, a), __builtin_bit_cast(rf_h16x8n, b), c, 0, 0, 0);
+}
+#else
+#define RF_H16 RF_BF16
+#define RF_H16_ONE2 0x3F803F80u
+typedef __attribute__((ext_vector_type(2))) __bf16 rf_h16x2;
+__device__ __forceinline__ float h2f(h16_t u) { return __uint_as_float(((unsigned)u) << 16); }
+__device__ __forceinline__ h16_t f2h(float x) {
   __bf16 b = (__bf16)x;  // v_cvt_pk_bf16_f32 on gfx950: round-to-nearest-even, NaN stays NaN
-  return __builtin_bit_cast(bf16_t, b);
+  return __builtin_bit_cast(h16_t, b);
 }
+__device__ __forceinline__ f32x4 rf_mfma16(h16x8 a, h16x8 b, f32x4 c, int, int, int) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+#endif
 
-// two floats -> packed bf16 pair (low half = a): ONE v_cvt_pk_bf16_f32.  (f2bf(a) | f2bf(b) << 16 compiles to two
+// two floats -> packed h16 pair (low half = a): ONE v_cvt_pk_{bf16,f16}_f32.  (f2h(a) | f2h(b) << 16 compiles to two
 // conversions plus a shift and an or.)
-typedef __attribute__((ext_vector_type(2))) float rf_f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 rf_bf16x2;
-__device__ __forceinline__ unsigned rf_pack2_bf16(float a, float b) {
+__device__ __forceinline__ unsigned rf_pack2_h16(float a, float b) {
   const rf_f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, rf_bf16x2));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, rf_h16x2));
+}
+// the two halves of a packed pair as floats
+__device__ __forceinline__ float rf_h16_lo(unsigned u) {
+#ifdef RF_H16_IS_F16
+  return (float)__builtin_bit_cast(rf_h16x2, u)[0];
+#else
+  return __uint_as_float(u << 16);
+#endif
+}
+__device__ __forceinline__ float rf_h16_hi(unsigned u) {
+#ifdef RF_H16_IS_F16
+  return (float)__builtin_bit_cast(rf_h16x2, u)[1];
+#else
+  return __uint_as_float(u & 0xffff0000u);
+#endif
 }
 
-// dtype-generic scalar load/store (T = activation dtype chosen by the host: fp32 or bf16)
+// dtype-generic scalar load/store (T = activation dtype chosen by the host: fp32 or the build's h16)
 __device__ __forceinline__ float ld(const void* p, int dtype, int64_t i) {
-  return dtype == RF_F32 ? ((const float*)p)[i] : bf2f(((const bf16_t*)p)[i]);
+  return dtype == RF_F32 ? ((const float*)p)[i] : h2f(((const h16_t*)p)[i]);
 }
 __device__ __forceinline__ void st(void* p, int dtype, int64_t i, float v) {
   if (dtype == RF_F32)
     ((float*)p)[i] = v;
   else
-    ((bf16_t*)p)[i] = f2bf(v);
+    ((h16_t*)p)[i] = f2h(v);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -31,9 +31,9 @@
 #define FV_DROWS 80
 
 struct FavorAttnP {
-  const bf16_t* qkv;  // [.., 3*inner] rows; q | k | v
-  const bf16_t* pc;   // [288][64] projection pre-scaled by d^-1/4, zero rows beyond 266
-  bf16_t* out;        // [.., inner]
+  const h16_t* qkv;  // [.., 3*inner] rows; q | k | v
+  const h16_t* pc;   // [288][64] projection pre-scaled by d^-1/4, zero rows beyond 266
+  h16_t* out;        // [.., inner]
   int64_t x_b, x_o, x_s;  // element strides of qkv for batch / outer index / sequence index
   int64_t x_h;            // element stride of qkv between heads (64 for rows holding all heads, Ls*64 for head-major tiles)
   int64_t o_b, o_o, o_s;  // same for out
@@ -42,7 +42,19 @@ struct FavorAttnP {
   int nchunks;  // sequence = nchunks * LS rows (ReLU kernel only; softmax kernel: 1)
   int dbg;      // timing experiments only: 1 = skip the phase-A MFMA loop, 2 = skip the phase-B loop
   float eps;
+  float ctx_scale;  // f16 build: 2^-ceil(log2(sequence length)), see FV_CS; 1 in the bf16 build
 };
+
+// fp16 range (librfmi_f16.so): the context sum_s k'[s,m] v[s,d] and the k' sums in its ones column grow with the sequence
+// length and would leave fp16's range (65504) for long sequences.  Numerator (q' ctx) and denominator (q' . sum_s k') of the
+// attention both carry the context linearly, so a common power-of-two factor cancels exactly: the f16 build publishes the
+// context scaled by 2^-ceil(log2(sequence length)) (a mean instead of a sum).  The bf16 build (fp32's exponent range)
+// compiles the factor out.
+#ifdef RF_H16_IS_F16
+#define FV_CS(x) ((x) * p.ctx_scale)
+#else
+#define FV_CS(x) (x)
+#endif
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -54,7 +66,7 @@ __device__ __forceinline__ void fv_glds(const void* src, void* lds_wave_base) {
 }
 
 // DMA a [nrows][64] bf16 tile (rows `stride` elements apart) into the swizzled LDS image at lds_off
-__device__ __forceinline__ void fv_load_tile(char* smem, int lds_off, const bf16_t* g, int64_t stride, int nrows,
+__device__ __forceinline__ void fv_load_tile(char* smem, int lds_off, const h16_t* g, int64_t stride, int nrows,
                                              int wave, int lane) {
   const int ninstr = nrows * 8 / 64;
   for (int it = wave; it < ninstr; it += 4) {
@@ -65,11 +77,11 @@ __device__ __forceinline__ void fv_load_tile(char* smem, int lds_off, const bf16
   }
 }
 
-__device__ __forceinline__ unsigned pack2(float a, float b) { return rf_pack2_bf16(a, b); }
-__device__ __forceinline__ float rbf(float x) { return bf2f(f2bf(x)); }
+__device__ __forceinline__ unsigned pack2(float a, float b) { return rf_pack2_h16(a, b); }
+__device__ __forceinline__ float rbf(float x) { return h2f(f2h(x)); }
 
 union Frag {
-  bf16x8 v;
+  h16x8 v;
   unsigned u[4];
   uint2 h[2];
 };
@@ -96,7 +108,7 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
   // the numerator tile of d-tile 4 carries the denominator in its row 64 -- both ride on the MFMA pipe.
   Frag ones;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) ones.u[k] = fr == 0 ? 0x3F803F80u : 0u;
+  for (int k = 0; k < 4; ++k) ones.u[k] = fr == 0 ? RF_H16_ONE2 : 0u;
 
   // one-time: projection image, zeroed ctx^T (its padded columns are read as MFMA operands)
   fv_load_tile(smem, PC_OFF, p.pc, FV_DH, FV_MPAD, wave, lane);
@@ -131,14 +143,14 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
     first = false;
     __syncthreads();  // K, V (and Pc on the first item) have landed; previous item fully consumed
     // Q fragments of this wave's rows straight from global; consumed in phase B, so phase A hides the latency
-    bf16x8 qf[ST][2];
+    h16x8 qf[ST][2];
     auto load_q = [&](int chunk) {
 #pragma unroll
       for (int t = 0; t < ST; ++t) {
         const int s = chunk * LS + (wave * ST + t) * 16 + fr;
-        const bf16_t* qrow = p.qkv + xb + p.q_off + (int64_t)s * p.x_s;
+        const h16_t* qrow = p.qkv + xb + p.q_off + (int64_t)s * p.x_s;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) qf[t][kk] = *(const bf16x8*)(qrow + (kk * 4 + fq) * 8);
+        for (int kk = 0; kk < 2; ++kk) qf[t][kk] = *(const h16x8*)(qrow + (kk * 4 + fq) * 8);
       }
     };
     load_q(0);
@@ -150,10 +162,10 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
         float a = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const bf16x8 x = *(const bf16x8*)(smem + K_OFF + s * 128 + c * 16);
+          const h16x8 x = *(const h16x8*)(smem + K_OFF + s * 128 + c * 16);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float f = bf2f((bf16_t)x[e]);
+            const float f = h2f((h16_t)x[e]);
             a = fmaf(f, f, a);
           }
         }
@@ -162,23 +174,23 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
     }
 
     // ---------------- phase A ----------------
-    bf16x8 pf[5][2];
+    h16x8 pf[5][2];
 #pragma unroll
     for (int j = 0; j < 5; ++j)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
-        if (j < nm) pf[j][kk] = *(const bf16x8*)(smem + PC_OFF + swz_off((m0t + j) * 16 + fr, kk * 4 + fq));
+        if (j < nm) pf[j][kk] = *(const h16x8*)(smem + PC_OFF + swz_off((m0t + j) * 16 + fr, kk * 4 + fq));
 
     if constexpr (SOFTMAX) {
       // pass 0: global max of the key logits over (s, m < 266)
       float mx = -INFINITY;
       for (int u = 0; u < NSB; ++u) {
-        bf16x8 kf[2][2];
+        h16x8 kf[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk)
-            kf[t][kk] = *(const bf16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + fr, kk * 4 + fq));
+            kf[t][kk] = *(const h16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + fr, kk * 4 + fq));
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           if (j < nm) {
@@ -186,8 +198,8 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
               f32x4 a = {0.f, 0.f, 0.f, 0.f};
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], pf[j][0], a, 0, 0, 0);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], pf[j][1], a, 0, 0, 0);
+              a = rf_mfma16(kf[t][0], pf[j][0], a, 0, 0, 0);
+              a = rf_mfma16(kf[t][1], pf[j][1], a, 0, 0, 0);
               if (valid) mx = fmaxf(mx, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
             }
           }
@@ -214,12 +226,12 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
       __syncthreads();
     }
     for (int u = 0; u < NSB; ++u) {
-      bf16x8 kf[2][2];
+      h16x8 kf[2][2];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
-          kf[t][kk] = *(const bf16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + fr, kk * 4 + fq));
+          kf[t][kk] = *(const h16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + fr, kk * 4 + fq));
       // V fragments (B operand, k = sequence): hardware-transposed reads of the row-major [s][d] image
       Frag vf[4];
       {
@@ -250,8 +262,8 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
           f32x4 a[2];
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            a[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], pf[j][0], init[t], 0, 0, 0);
-            a[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], pf[j][1], a[t], 0, 0, 0);
+            a[t] = rf_mfma16(kf[t][0], pf[j][0], init[t], 0, 0, 0);
+            a[t] = rf_mfma16(kf[t][1], pf[j][1], a[t], 0, 0, 0);
           }
           float f[2][4];
 #pragma unroll
@@ -277,8 +289,8 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
           kfr.u[3] = pack2(f[1][2], f[1][3]);
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            ctx[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr.v, vf[i].v, ctx[j][i], 0, 0, 0);
-          ctx[j][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr.v, ones.v, ctx[j][4], 0, 0, 0);
+            ctx[j][i] = rf_mfma16(kfr.v, vf[i].v, ctx[j][i], 0, 0, 0);
+          ctx[j][4] = rf_mfma16(kfr.v, ones.v, ctx[j][4], 0, 0, 0);
         }
       }
     }
@@ -290,8 +302,8 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
 #pragma unroll
         for (int i = 0; i < FV_DT; ++i) {
           uint2 w;
-          w.x = pack2(ctx[j][i][0], ctx[j][i][1]);
-          w.y = pack2(ctx[j][i][2], ctx[j][i][3]);
+          w.x = pack2(FV_CS(ctx[j][i][0]), FV_CS(ctx[j][i][1]));
+          w.y = pack2(FV_CS(ctx[j][i][2]), FV_CS(ctx[j][i][3]));
           *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ((m0t + j) * 16 + 4 * fq) * 2) = w;
         }
       }
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float f = bf2f((bf16_t)qf[t][kk][e]);
+            const float f = h2f((h16_t)qf[t][kk][e]);
             a = fmaf(f, f, a);
           }
         a += __shfl_xor(a, 16, 64);
@@ -334,14 +346,14 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
       }
       // pass 0: per-row max of the query logits over m < 266
       for (int j = 0; j < FV_MT; ++j) {
-        bf16x8 pfr[2];
+        h16x8 pfr[2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) pfr[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off(j * 16 + fr, kk * 4 + fq));
+        for (int kk = 0; kk < 2; ++kk) pfr[kk] = *(const h16x8*)(smem + PC_OFF + swz_off(j * 16 + fr, kk * 4 + fq));
 #pragma unroll
         for (int t = 0; t < ST; ++t) {
           f32x4 a = {0.f, 0.f, 0.f, 0.f};
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[0], qf[t][0], a, 0, 0, 0);
-          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[1], qf[t][1], a, 0, 0, 0);
+          a = rf_mfma16(pfr[0], qf[t][0], a, 0, 0, 0);
+          a = rf_mfma16(pfr[1], qf[t][1], a, 0, 0, 0);
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (j * 16 + 4 * fq + r < FV_M) rmax[t] = fmaxf(rmax[t], a[r]);
@@ -375,13 +387,13 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
             for (int r = 0; r < 4; ++r) f[jj][t][r] = 0.f;
         } else {
           const int j = 2 * u + jj;
-          bf16x8 pfr[2];
+          h16x8 pfr[2];
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk) pfr[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off(j * 16 + fr, kk * 4 + fq));
+          for (int kk = 0; kk < 2; ++kk) pfr[kk] = *(const h16x8*)(smem + PC_OFF + swz_off(j * 16 + fr, kk * 4 + fq));
 #pragma unroll
           for (int t = 0; t < ST; ++t) {
-            f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[0], qf[t][0], qinit[t], 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[1], qf[t][1], a, 0, 0, 0);
+            f32x4 a = rf_mfma16(pfr[0], qf[t][0], qinit[t], 0, 0, 0);
+            a = rf_mfma16(pfr[1], qf[t][1], a, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float x;
@@ -411,7 +423,7 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
         qfr.u[3] = pack2(f[1][t][2], f[1][t][3]);
 #pragma unroll
         for (int i = 0; i < FV_DT; ++i)
-          num[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[i].v, qfr.v, num[i][t], 0, 0, 0);
+          num[i][t] = rf_mfma16(cf[i].v, qfr.v, num[i][t], 0, 0, 0);
       }
     };
     for (int u = 0; u < (FV_MT - 1) / 2; ++u) mblock(u, std::false_type{});
@@ -422,7 +434,7 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
       const float dn = __shfl(num[4][t][0], fr, 64);  // row d = 64 lives in register 0 of the fq == 0 lanes
       const float inv = 1.f / dn;
       const int s = qc * LS + (wave * ST + t) * 16 + fr;
-      bf16_t* orow = p.out + ob + (int64_t)s * p.o_s;
+      h16_t* orow = p.out + ob + (int64_t)s * p.o_s;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         uint2 w;
@@ -500,17 +512,17 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
   const f32x4 epsv = {p.eps, p.eps, p.eps, p.eps};
   Frag ones;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) ones.u[k] = fr == 0 ? 0x3F803F80u : 0u;
+  for (int k = 0; k < 4; ++k) ones.u[k] = fr == 0 ? RF_H16_ONE2 : 0u;
 
   // [nrows][64] bf16 tile -> swizzled LDS image; a wave's instruction covers 8 rows (row = 8*it + lane/8, rows & 7 == lane/8)
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  auto load_tile8 = [&](int lds_off, const bf16_t* gp, int64_t stride, auto nrows_tag) {
+  auto load_tile8 = [&](int lds_off, const h16_t* gp, int64_t stride, auto nrows_tag) {
     constexpr int NI = decltype(nrows_tag)::value * 8 / 64;
     int ln = lane;  // opaque: the per-lane source offsets are rebuilt at every call instead of living in (spilled) registers
     asm volatile("" : "+v"(ln));
     const int dma_row = ln >> 3;
     const int dma_col = ((ln & 7) ^ dma_row) * 8;
-    const bf16_t* g0 = gp + (int64_t)dma_row * stride + dma_col;
+    const h16_t* g0 = gp + (int64_t)dma_row * stride + dma_col;
 #pragma unroll
     for (int k = 0; k < (NI + 7) / 8; ++k) {
       const int it = wave + 8 * k;
@@ -556,7 +568,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
     first = false;
     fv_lds_barrier();
     FV_STAMP(0)
-    bf16x8 qf[STB][2];
+    h16x8 qf[STB][2];
     auto load_q = [&](int chunk) {
       int frq = fr, fqq = fq;  // opaque copies: keeps the row / chunk offsets out of the kernel-long live ranges
       asm volatile("" : "+v"(frq), "+v"(fqq));
@@ -564,9 +576,9 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
 #pragma unroll
         for (int t = 0; t < STB; ++t) {
           const int s = chunk * LS + (wave * STB + t) * 16 + frq;
-          const bf16_t* qrow = p.qkv + xb + p.q_off + (int64_t)s * p.x_s;
+          const h16_t* qrow = p.qkv + xb + p.q_off + (int64_t)s * p.x_s;
 #pragma unroll
-          for (int kk = 0; kk < 2; ++kk) qf[t][kk] = *(const bf16x8*)(qrow + (kk * 4 + fqq) * 8);
+          for (int kk = 0; kk < 2; ++kk) qf[t][kk] = *(const h16x8*)(qrow + (kk * 4 + fqq) * 8);
         }
       }
     };
@@ -580,10 +592,10 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
         float a = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-          const bf16x8 x = *(const bf16x8*)(smem + K_OFF + s * 128 + c * 16);
+          const h16x8 x = *(const h16x8*)(smem + K_OFF + s * 128 + c * 16);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float f = bf2f((bf16_t)x[e]);
+            const float f = h2f((h16_t)x[e]);
             a = fmaf(f, f, a);
           }
         }
@@ -592,24 +604,24 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
       // pass 0: global max of the key logits (this wave: its feature tiles x its sequence half)
       float mx = -INFINITY;
       for (int u = hs * NSBH; u < (hs + 1) * NSBH; ++u) {
-        bf16x8 kf[2][2];
+        h16x8 kf[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk)
-            kf[t][kk] = *(const bf16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + frS, kk * 4 + fqS));
+            kf[t][kk] = *(const h16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + frS, kk * 4 + fqS));
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           if (j < nm) {
-            bf16x8 pfj[2];
+            h16x8 pfj[2];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) pfj[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off((m0t + j) * 16 + frS, kk * 4 + fqS));
+            for (int kk = 0; kk < 2; ++kk) pfj[kk] = *(const h16x8*)(smem + PC_OFF + swz_off((m0t + j) * 16 + frS, kk * 4 + fqS));
             const bool valid = (m0t + j) * 16 + frS < FV_M;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
               f32x4 a = {0.f, 0.f, 0.f, 0.f};
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], pfj[0], a, 0, 0, 0);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], pfj[1], a, 0, 0, 0);
+              a = rf_mfma16(kf[t][0], pfj[0], a, 0, 0, 0);
+              a = rf_mfma16(kf[t][1], pfj[1], a, 0, 0, 0);
               if (valid) mx = fmaxf(mx, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
             }
           }
@@ -637,12 +649,12 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
         __syncthreads();
       }
       for (int u = hs * NSBH; u < ((p.dbg & 1) ? hs * NSBH : (hs + 1) * NSBH); ++u) {
-        bf16x8 kf[2][2];
+        h16x8 kf[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk)
-            kf[t][kk] = *(const bf16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + fr, kk * 4 + fq));
+            kf[t][kk] = *(const h16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + fr, kk * 4 + fq));
         Frag vf[4];
         {
           const int p4 = fr & 3;
@@ -668,14 +680,14 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           if (j < nm) {
-            bf16x8 pfj[2];  // re-read per s-block: 8 registers instead of 40 resident ones
+            h16x8 pfj[2];  // re-read per s-block: 8 registers instead of 40 resident ones
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) pfj[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off((m0t + j) * 16 + fr, kk * 4 + fq));
+            for (int kk = 0; kk < 2; ++kk) pfj[kk] = *(const h16x8*)(smem + PC_OFF + swz_off((m0t + j) * 16 + fr, kk * 4 + fq));
             f32x4 a[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-              a[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][0], pfj[0], init[t], 0, 0, 0);
-              a[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][1], pfj[1], a[t], 0, 0, 0);
+              a[t] = rf_mfma16(kf[t][0], pfj[0], init[t], 0, 0, 0);
+              a[t] = rf_mfma16(kf[t][1], pfj[1], a[t], 0, 0, 0);
             }
             float f[2][4];
 #pragma unroll
@@ -700,8 +712,8 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
             kfr.u[3] = pack2(f[1][2], f[1][3]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-              ctx[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr.v, vf[i].v, ctx[j][i], 0, 0, 0);
-            ctx[j][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr.v, ones.v, ctx[j][4], 0, 0, 0);
+              ctx[j][i] = rf_mfma16(kfr.v, vf[i].v, ctx[j][i], 0, 0, 0);
+            ctx[j][4] = rf_mfma16(kfr.v, ones.v, ctx[j][4], 0, 0, 0);
           }
         }
       }
@@ -717,8 +729,8 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
 #pragma unroll
         for (int i = 0; i < FV_DT; ++i) {
           uint2 w;
-          w.x = pack2(ctx[j][i][0], ctx[j][i][1]);
-          w.y = pack2(ctx[j][i][2], ctx[j][i][3]);
+          w.x = pack2(FV_CS(ctx[j][i][0]), FV_CS(ctx[j][i][1]));
+          w.y = pack2(FV_CS(ctx[j][i][2]), FV_CS(ctx[j][i][3]));
           *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq)) = w;
         }
       }
@@ -734,8 +746,8 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
 #pragma unroll
         for (int i = 0; i < FV_DT; ++i) {
           uint2 w;
-          w.x = pack2(ctx[j][i][0] + bf2f((bf16_t)(o[i].x & 0xffff)), ctx[j][i][1] + bf2f((bf16_t)(o[i].x >> 16)));
-          w.y = pack2(ctx[j][i][2] + bf2f((bf16_t)(o[i].y & 0xffff)), ctx[j][i][3] + bf2f((bf16_t)(o[i].y >> 16)));
+          w.x = pack2(FV_CS(ctx[j][i][0]) + rf_h16_lo(o[i].x), FV_CS(ctx[j][i][1]) + rf_h16_hi(o[i].x));
+          w.y = pack2(FV_CS(ctx[j][i][2]) + rf_h16_lo(o[i].y), FV_CS(ctx[j][i][3]) + rf_h16_hi(o[i].y));
           *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq)) = w;
         }
       }
@@ -787,7 +799,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
-                const float f = bf2f((bf16_t)qf[t][kk][e]);
+                const float f = h2f((h16_t)qf[t][kk][e]);
                 a = fmaf(f, f, a);
               }
             a += __shfl_xor(a, 16, 64);
@@ -796,14 +808,14 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
             rmax[t] = -INFINITY;
           }
           for (int j = 0; j < FV_MT; ++j) {
-            bf16x8 pfr[2];
+            h16x8 pfr[2];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) pfr[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off(j * 16 + fr, kk * 4 + fq));
+            for (int kk = 0; kk < 2; ++kk) pfr[kk] = *(const h16x8*)(smem + PC_OFF + swz_off(j * 16 + fr, kk * 4 + fq));
 #pragma unroll
             for (int t = 0; t < STB; ++t) {
               f32x4 a = {0.f, 0.f, 0.f, 0.f};
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[0], qf[t][0], a, 0, 0, 0);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[1], qf[t][1], a, 0, 0, 0);
+              a = rf_mfma16(pfr[0], qf[t][0], a, 0, 0, 0);
+              a = rf_mfma16(pfr[1], qf[t][1], a, 0, 0, 0);
 #pragma unroll
               for (int r = 0; r < 4; ++r)
                 if (j * 16 + 4 * fq + r < FV_M) rmax[t] = fmaxf(rmax[t], a[r]);
@@ -834,13 +846,13 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
                 for (int r = 0; r < 4; ++r) f[jj][t][r] = 0.f;
             } else {
               const int j = 2 * u + jj;
-              bf16x8 pfr[2];
+              h16x8 pfr[2];
 #pragma unroll
-              for (int kk = 0; kk < 2; ++kk) pfr[kk] = *(const bf16x8*)(smem + PC_OFF + swz_off(j * 16 + fr, kk * 4 + fq));
+              for (int kk = 0; kk < 2; ++kk) pfr[kk] = *(const h16x8*)(smem + PC_OFF + swz_off(j * 16 + fr, kk * 4 + fq));
 #pragma unroll
               for (int t = 0; t < STB; ++t) {
-                f32x4 a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[0], qf[t][0], qinit[t], 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pfr[1], qf[t][1], a, 0, 0, 0);
+                f32x4 a = rf_mfma16(pfr[0], qf[t][0], qinit[t], 0, 0, 0);
+                a = rf_mfma16(pfr[1], qf[t][1], a, 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   float x;
@@ -857,7 +869,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
           Frag cf[FV_DT];  // one 16-byte read per fragment: the image keeps a lane's 8 k-slots (2 tiles x 4 rows) adjacent
 #pragma unroll
           for (int i = 0; i < FV_DT; ++i)
-            cf[i].v = *(const bf16x8*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + (32 * u + 8 * fq) * 2);
+            cf[i].v = *(const h16x8*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + (32 * u + 8 * fq) * 2);
 #pragma unroll
           for (int t = 0; t < STB; ++t) {
             Frag qfr;
@@ -867,7 +879,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
             qfr.u[3] = pack2(f[1][t][2], f[1][t][3]);
 #pragma unroll
             for (int i = 0; i < FV_DT; ++i)
-              num[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cf[i].v, qfr.v, num[i][t], 0, 0, 0);
+              num[i][t] = rf_mfma16(cf[i].v, qfr.v, num[i][t], 0, 0, 0);
           }
         };
         for (int u = 0; u < ((p.dbg & 2) ? 0 : (FV_MT - 1) / 2); ++u) mblock(u, std::false_type{});
@@ -878,7 +890,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
           const float dn = __shfl(num[4][t][0], fr, 64);
           const float inv = 1.f / dn;
           const int s = qc * LS + (wave * STB + t) * 16 + fr;
-          bf16_t* orow = p.out + ob + (int64_t)s * p.o_s;
+          h16_t* orow = p.out + ob + (int64_t)s * p.o_s;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             uint2 w;
@@ -944,9 +956,9 @@ extern "C" int rf_favor_attention(const void* qkv, const void* pc, void* out, co
   if (x_strides[3] % 8) return RF_EALIGN;
   if (q_off % 8 || k_off % 8 || v_off % 8) return RF_EALIGN;
   FavorAttnP p;
-  p.qkv = (const bf16_t*)qkv;
-  p.pc = (const bf16_t*)pc;
-  p.out = (bf16_t*)out;
+  p.qkv = (const h16_t*)qkv;
+  p.pc = (const h16_t*)pc;
+  p.out = (h16_t*)out;
   p.x_b = x_strides[0]; p.x_o = x_strides[1]; p.x_s = x_strides[2]; p.x_h = x_strides[3];
   p.o_b = o_strides[0]; p.o_o = o_strides[1]; p.o_s = o_strides[2];
   p.q_off = q_off; p.k_off = k_off; p.v_off = v_off;
@@ -954,6 +966,10 @@ extern "C" int rf_favor_attention(const void* qkv, const void* pc, void* out, co
   p.nitems = n_b * n_o * n_h;
   p.eps = eps;
   p.nchunks = nchunks;
+  p.ctx_scale = 1.0f;
+#ifdef RF_H16_IS_F16
+  for (int n = 1; n < seq_len; n <<= 1) p.ctx_scale *= 0.5f;
+#endif
   static const int dbg = getenv("RF_FAVOR_DBG") ? atoi(getenv("RF_FAVOR_DBG")) : 0;
   p.dbg = dbg;
   hipStream_t s = (hipStream_t)stream;

@@ -124,12 +124,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_bf16_kernel(const Gemm
   unsigned long long st0 = 0, st1 = 0, st2 = 0, st_w = 0, st_s = 0, st_x = 0;
   if (p.stamps) st0 = __builtin_amdgcn_s_memrealtime();
 
-  const bf16_t* Ab = (const bf16_t*)d.A + (AMODE == RF_AMODE_CONV3X3 ? 0 : z0 * d.a_bs[0] + z1 * d.a_bs[1] + z2 * d.a_bs[2]);
-  const bf16_t* Bb = (const bf16_t*)d.B + z0 * d.b_bs[0] + z1 * d.b_bs[1] + z2 * d.b_bs[2];
+  const h16_t* Ab = (const h16_t*)d.A + (AMODE == RF_AMODE_CONV3X3 ? 0 : z0 * d.a_bs[0] + z1 * d.a_bs[1] + z2 * d.a_bs[2]);
+  const h16_t* Bb = (const h16_t*)d.B + z0 * d.b_bs[0] + z1 * d.b_bs[1] + z2 * d.b_bs[2];
 
   // ---- per-lane staging state -------------------------------------------------------------
-  const bf16_t* a_src[A_PW];
-  const bf16_t* b_src[B_PW];
+  const h16_t* a_src[A_PW];
+  const h16_t* b_src[B_PW];
   int a_ij[A_PW];  // conv: (i << 16) | j of the row's pixel
 #pragma unroll
   for (int t = 0; t < A_PW; ++t) {
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_bf16_kernel(const Gemm
     }
   };
   a_koff_update();
-  const bf16_t* const zsrc = (const bf16_t*)g_rf_zero16;
+  const h16_t* const zsrc = (const h16_t*)g_rf_zero16;
 
   auto stage = [&](int buf) {
     char* a_lds = smem + buf * STAGE_BYTES;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_bf16_kernel(const Gemm
           const int ii = (a_ij[t] >> 16) + cdi, jj = (a_ij[t] & 0xffff) + cdj;
           ok = ok && ii >= 0 && ii < d.conv_h && jj >= 0 && jj < d.conv_w;
         }
-        const bf16_t* src = ok ? a_src[t] + a_koff : zsrc;
+        const h16_t* src = ok ? a_src[t] + a_koff : zsrc;
         glds16(src, a_lds + instr * 1024);
       }
     }
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_bf16_kernel(const Gemm
     for (int t = 0; t < B_PW; ++t) {
       const int instr = t * NW + wave;
       if ((B_INSTR % NW == 0) || instr < B_INSTR) {
-        const bf16_t* src = kvalid ? b_src[t] + b_koff : zsrc;
+        const h16_t* src = kvalid ? b_src[t] + b_koff : zsrc;
         glds16(src, b_lds + instr * 1024);
       }
     }
@@ -259,23 +259,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_bf16_kernel(const Gemm
     const char* b_lds = a_lds + A_BYTES;
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
-      bf16x8 af[WM], bfr[WN];
+      h16x8 af[WM], bfr[WN];
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
         const int row = wm * TM + i * 16 + fr;
-        af[i] = *(const bf16x8*)(a_lds + (row * SPR + ((kk * 4 + fq) ^ swz<BK>(row))) * 16);
+        af[i] = *(const h16x8*)(a_lds + (row * SPR + ((kk * 4 + fq) ^ swz<BK>(row))) * 16);
       }
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int row = wn * TN + j * 16 + fr;
-        bfr[j] = *(const bf16x8*)(b_lds + (row * SPR + ((kk * 4 + fq) ^ swz<BK>(row))) * 16);
+        bfr[j] = *(const h16x8*)(b_lds + (row * SPR + ((kk * 4 + fq) ^ swz<BK>(row))) * 16);
       }
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
           // weight tile as MFMA-A, activation tile as MFMA-B: D[n_local][m_local]
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = rf_mfma16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     }
   }
 
@@ -374,8 +374,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_bf16_kernel(const Gemm
                   *(float4*)(lrow + nl * 4) = make_float4(v0, v1, v2, v3);
                 } else {
                   uint2 o;
-                  o.x = rf_pack2_bf16(v0, v1);
-                  o.y = rf_pack2_bf16(v2, v3);
+                  o.x = rf_pack2_h16(v0, v1);
+                  o.y = rf_pack2_h16(v2, v3);
                   *(uint2*)(lrow + nl * 2) = o;
                 }
               }
@@ -394,8 +394,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_bf16_kernel(const Gemm
                   *(float4*)(lrow + nl * 4) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                   uint2 o;
-                  o.x = rf_pack2_bf16(v[0], v[1]);
-                  o.y = rf_pack2_bf16(v[2], v[3]);
+                  o.x = rf_pack2_h16(v[0], v[1]);
+                  o.y = rf_pack2_h16(v[2], v[3]);
                   *(uint2*)(lrow + nl * 2) = o;
                 }
               }
@@ -467,9 +467,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_bf16_kernel(const Gemm
                 *(f32x4*)((float*)d.C + coff[g]) = v;
             } else {
               if (p.nt_store)
-                __builtin_nontemporal_store(vv[g], (f32x4*)((bf16_t*)d.C + coff[g]));
+                __builtin_nontemporal_store(vv[g], (f32x4*)((h16_t*)d.C + coff[g]));
               else
-                *(f32x4*)((bf16_t*)d.C + coff[g]) = vv[g];
+                *(f32x4*)((h16_t*)d.C + coff[g]) = vv[g];
             }
           }
         }
@@ -603,9 +603,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP p) {
           *(float4*)((float*)d.C + o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
           uint2 w;
-          w.x = rf_pack2_bf16(v[0], v[1]);
-          w.y = rf_pack2_bf16(v[2], v[3]);
-          *(uint2*)((bf16_t*)d.C + o) = w;
+          w.x = rf_pack2_h16(v[0], v[1]);
+          w.y = rf_pack2_h16(v[2], v[3]);
+          *(uint2*)((h16_t*)d.C + o) = w;
         }
         continue;
       }
@@ -772,7 +772,7 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
     g_last_family = 0;
     return rf_launch_status();
   }
-  if (d.ab_dtype != RF_BF16) return RF_EINVAL;
+  if (d.ab_dtype != RF_H16) return RF_EINVAL;
   // DMA needs 16-byte aligned sources: all element strides multiples of 8, K chunks multiples of 8
   auto al8 = [](int64_t v) { return (v % 8) == 0; };
   if (((uintptr_t)d.A % 16) || ((uintptr_t)d.B % 16)) return RF_EALIGN;
@@ -809,7 +809,7 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
       if (rf_gemm_fast_try(d2, batch, &rc, stream)) {
         g_last_family = 3;
         if (rc != 0) return rc;
-        return rf_layernorm(d.C, RF_F32, d.c_ri, d.ln_out, RF_BF16, d.N, d.M, d.N, d.ln_gamma, d.ln_beta, d.ln_eps, 1, RF_ACT_NONE, stream);
+        return rf_layernorm(d.C, RF_F32, d.c_ri, d.ln_out, RF_H16, d.N, d.M, d.N, d.ln_gamma, d.ln_beta, d.ln_eps, 1, RF_ACT_NONE, stream);
       }
     }
   }
@@ -866,5 +866,5 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
 #undef RF_CASE
   g_last_family = d.a_mode == RF_AMODE_CONV3X3 ? 2 : 1;
   if (rc != 0 || !want_ln) return rc;
-  return rf_layernorm(d.C, RF_F32, d.c_ri, d.ln_out, RF_BF16, d.N, d.M, d.N, d.ln_gamma, d.ln_beta, d.ln_eps, 1, RF_ACT_NONE, stream);
+  return rf_layernorm(d.C, RF_F32, d.c_ri, d.ln_out, RF_H16, d.N, d.M, d.N, d.ln_gamma, d.ln_beta, d.ln_eps, 1, RF_ACT_NONE, stream);
 }

@@ -20,8 +20,8 @@
 static __device__ __attribute__((aligned(16))) unsigned int g_fast_zero16[4];  // zero source for K-tail DMA lanes
 
 struct FastP {
-  const bf16_t* A;
-  const bf16_t* B;
+  const h16_t* A;
+  const h16_t* B;
   void* C;
   const float* bias;      // fp32 [N] or null
   const float* residual;  // fp32 [M, N] (ldc) or null
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
     //   waves 0-3:  R0 M0 R1 M1 | R0 M0 R1 M1 |        waves 4-7:  M1' R0 M0 R1 | M1' R0 M0 R1 | ... M1'
     // (one barrier per K step as before; the carried fragments are in registers, and a lagging wave retires its R1 reads
     // before the barrier, so the buffer can be re-staged right behind it).
-    bf16x8 af[WM] = {}, bfr[WN] = {};
+    h16x8 af[WM] = {}, bfr[WN] = {};
     auto read_frags = [&](int kk) {
       if (p.dbg & 8) return;
       const char* a_lds = smem + buf * STAGE_BYTES;
@@ -184,12 +184,12 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
         const int row = wm * TM + i * 16 + fr;
-        af[i] = *(const bf16x8*)(a_lds + (row * 8 + ((kk * 4 + fq) ^ ((row >> 1) & 7))) * 16);
+        af[i] = *(const h16x8*)(a_lds + (row * 8 + ((kk * 4 + fq) ^ ((row >> 1) & 7))) * 16);
       }
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int row = wn * TN + j * 16 + fr;
-        bfr[j] = *(const bf16x8*)(b_lds + (row * 8 + ((kk * 4 + fq) ^ ((row >> 1) & 7))) * 16);
+        bfr[j] = *(const h16x8*)(b_lds + (row * 8 + ((kk * 4 + fq) ^ ((row >> 1) & 7))) * 16);
       }
     };
     auto mfmas = [&]() {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
 #pragma unroll
         for (int j = 0; j < WN; ++j)
           // weight tile as MFMA-A, activation tile as MFMA-B: lane holds C[m = ..+fr][n = ..+4*fq .. +3]
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = rf_mfma16(bfr[j], af[i], acc[i][j], 0, 0, 0);
     };
     const bool half_tail = k_tail && (p.K % BK) <= 32;  // K tail of <= 32: the second half of the last step is all zeros
     for (int kt = 0; kt < nk; ++kt) {
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
                 *(f32x4*)(lrow + nl * 4) = (f32x4){v0, v1, v2, v3};
               } else {
                 uint2 o;
-                o.x = rf_pack2_bf16(v0, v1);
-                o.y = rf_pack2_bf16(v2, v3);
+                o.x = rf_pack2_h16(v0, v1);
+                o.y = rf_pack2_h16(v2, v3);
                 *(uint2*)(lrow + nl * 2) = o;
               }
             }
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
       constexpr int WSTRIDE = RP * PITCHW > 16 * PITCHB ? RP * PITCHW : 16 * PITCHB;
       char* const stripb = smem + (buf ^ 1) * STAGE_BYTES + wave * WSTRIDE;
       const float* const gam = (const float*)(smem + GB_OFF) + wn * TN + 4 * fq;
-      bf16_t* const Lw = (bf16_t*)p.ln_out + (int64_t)(m0 + wm * TM) * BN + wn * TN;
+      h16_t* const Lw = (h16_t*)p.ln_out + (int64_t)(m0 + wm * TM) * BN + wn * TN;
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
         __builtin_amdgcn_sched_barrier(0);
@@ -403,8 +403,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = (acc[i][j][e] - ln_mean[i]) * ln_rstd[i] * g4[e] + b4[e];
           uint2 w;
-          w.x = rf_pack2_bf16(o[0], o[1]);
-          w.y = rf_pack2_bf16(o[2], o[3]);
+          w.x = rf_pack2_h16(o[0], o[1]);
+          w.y = rf_pack2_h16(o[2], o[3]);
           *(uint2*)(lrow + (j * 16 + 4 * fq) * 2) = w;
         }
         asm volatile("" ::: "memory");
@@ -463,10 +463,10 @@ int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
   *rc = 0;
   static const bool no_fast = rf_env_flag("RF_NO_FAST_GEMM"), no_nt = rf_env_flag("RF_NO_NT_STORE"), no_lag = rf_env_flag("RF_GEMM_NO_LAG");
   if (no_fast) return 0;
-  if (d.ab_dtype != RF_BF16 || d.a_mode != RF_AMODE_PLAIN || batch != 1) return 0;
+  if (d.ab_dtype != RF_H16 || d.a_mode != RF_AMODE_PLAIN || batch != 1) return 0;
   if (d.a_rc > 0 || d.b_rc > 0 || d.kc != d.K) return 0;
   const bool cs = d.c_rc > 0 || d.c_cc > 0;  // split-C layout: bf16 output in whole 16-byte chunks, no residual / LayerNorm
-  if (cs && (d.c_dtype != RF_BF16 || d.residual || d.ln_out || (d.c_cc > 0 && (d.c_cc % 8 || d.c_co % 8)) ||
+  if (cs && (d.c_dtype != RF_H16 || d.residual || d.ln_out || (d.c_cc > 0 && (d.c_cc % 8 || d.c_co % 8)) ||
              (d.c_rc > 0 && d.c_ro % 8)))
     return 0;
   if (d.M % 256 != 0 || d.M < 16384 || d.K < 64 || d.K % 8 != 0 || d.alpha != 1.0f) return 0;
@@ -485,8 +485,8 @@ int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
                     : (d.N % 256 == 0 ? 256 : (d.N % 288 == 0 ? 288 : (d.N % 192 == 0 ? 192 : (d.N % 128 == 0 ? 128 : 0))));
   if (!bn) return 0;
   FastP p;
-  p.A = (const bf16_t*)d.A;
-  p.B = (const bf16_t*)d.B;
+  p.A = (const h16_t*)d.A;
+  p.B = (const h16_t*)d.B;
   p.C = d.C;
   p.bias = d.bias_mode == RF_BIAS_COL ? d.bias : nullptr;
   p.residual = d.residual;

@@ -25,9 +25,9 @@
 static __device__ __attribute__((aligned(16))) unsigned int g_wreg_zero16[4];
 
 struct WregP {
-  const bf16_t* A;  // [M, K] row-major (lda)
-  const bf16_t* B;  // [N, K] row-major (ldb): nn.Linear weight
-  bf16_t* C;        // [M, N] bf16 (ldc), or split layout (c_rc / c_cc, see rf_gemm_desc)
+  const h16_t* A;  // [M, K] row-major (lda)
+  const h16_t* B;  // [N, K] row-major (ldb): nn.Linear weight
+  h16_t* C;        // [M, N] bf16 (ldc), or split layout (c_rc / c_cc, see rf_gemm_desc)
   const float* bias;
   int M, N, K;
   int lda, ldb, ldc;
@@ -44,7 +44,7 @@ __device__ __forceinline__ void wreg_glds16(const void* src, void* lds_wave_base
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ unsigned wreg_pack2(float a, float b) { return rf_pack2_bf16(a, b); }
+__device__ __forceinline__ unsigned wreg_pack2(float a, float b) { return rf_pack2_h16(a, b); }
 
 // KS: K / 32;  TMR: rows per activation tile;  WR: wave rows (8 / WR wave columns);  WCT: 16-column tiles per wave;
 // NSTG: ring depth;  CS: split-C addressing
@@ -91,15 +91,15 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(const WregP p) {
   auto swz = [](int row) { return S % 16 == 0 ? (row & 15) : ((0x6C >> (((row >> 2) & 3) * 2)) & 3); };
 
   // ---- weights of this wave: W[n0 + 16 j + fr][32 s + 8 fq .. +7] as MFMA-A fragments, resident for the whole kernel ----
-  bf16x8 wf[WCT][KS];
+  h16x8 wf[WCT][KS];
   f32x4 bias4[WCT];
   {
 #pragma unroll
     for (int j = 0; j < WCT; ++j) {
       const int n = n0 + j * 16 + fr;
-      const bf16_t* wrow = p.B + (int64_t)(n < p.N ? n : p.N - 1) * p.ldb + fq * 8;
+      const h16_t* wrow = p.B + (int64_t)(n < p.N ? n : p.N - 1) * p.ldb + fq * 8;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) wf[j][s] = *(const bf16x8*)(wrow + s * 32);
+      for (int s = 0; s < KS; ++s) wf[j][s] = *(const h16x8*)(wrow + s * 32);
       bias4[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (p.bias && n0 + j * 16 + 4 * fq + 3 < p.N) bias4[j] = *(const f32x4*)(p.bias + n0 + j * 16 + 4 * fq);
     }
@@ -175,15 +175,15 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(const WregP p) {
     {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        bf16x8 af[WRT];
+        h16x8 af[WRT];
 #pragma unroll
-        for (int i = 0; i < WRT; ++i) af[i] = *(const bf16x8*)(st + a_rd[i] + (s >> 2) * 256 + s_rd[s & 3]);
+        for (int i = 0; i < WRT; ++i) af[i] = *(const h16x8*)(st + a_rd[i] + (s >> 2) * 256 + s_rd[s & 3]);
 #pragma unroll
         for (int i = 0; i < WRT; ++i)
 #pragma unroll
           for (int j = 0; j < WCT; ++j)
             // weight tile as MFMA-A, activation tile as MFMA-B: lane holds C[m = 16 i + fr][n = 16 j + 4 fq .. +3]
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][s], af[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = rf_mfma16(wf[j][s], af[i], acc[i][j], 0, 0, 0);
       }
     }
     // ---- epilogue: wave-private strip (in-order LDS per wave: no barrier), 16-byte row-contiguous stores -----------
@@ -248,7 +248,7 @@ int rf_gemm_wreg_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
   *rc = 0;
   static const bool off = rf_env_flag("RF_NO_WREG_GEMM");
   if (off) return 0;
-  if (d.ab_dtype != RF_BF16 || d.c_dtype != RF_BF16 || d.a_mode != RF_AMODE_PLAIN || batch != 1) return 0;
+  if (d.ab_dtype != RF_H16 || d.c_dtype != RF_H16 || d.a_mode != RF_AMODE_PLAIN || batch != 1) return 0;
   if (d.a_rc > 0 || d.b_rc > 0 || d.kc != d.K || d.residual || d.ln_out || d.alpha != 1.0f) return 0;
   if (d.K != 288 && d.K != 384) return 0;
   if (d.M % 64 != 0 || d.M < 16384 || d.N % 128 != 0 || d.N < 256) return 0;
@@ -260,7 +260,7 @@ int rf_gemm_wreg_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
   const bool cs = d.c_rc > 0 || d.c_cc > 0;
   if (cs && ((d.c_cc > 0 && (d.c_cc % 8 || d.c_co % 8)) || (d.c_rc > 0 && d.c_ro % 8))) return 0;
   WregP p;
-  p.A = (const bf16_t*)d.A; p.B = (const bf16_t*)d.B; p.C = (bf16_t*)d.C;
+  p.A = (const h16_t*)d.A; p.B = (const h16_t*)d.B; p.C = (h16_t*)d.C;
   p.bias = d.bias_mode == RF_BIAS_COL ? d.bias : nullptr;
   p.M = d.M; p.N = d.N; p.K = d.K;
   p.lda = (int)d.a_ri; p.ldb = (int)d.b_ri; p.ldc = (int)d.c_ri;

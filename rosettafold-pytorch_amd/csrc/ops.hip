@@ -5,7 +5,7 @@
 #include "common.h"
 
 #define RF_CHECK_DT(dt) \
-  if ((dt) != RF_F32 && (dt) != RF_BF16) return RF_EINVAL
+  if ((dt) != RF_F32 && (dt) != RF_H16) return RF_EINVAL
 
 static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
@@ -29,18 +29,17 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // 4-element accessors: 16-byte (fp32) / 8-byte (bf16)
 __device__ __forceinline__ float4 ld4(const void* p, int dt, int64_t e) {
   if (dt == RF_F32) return *(const float4*)((const float*)p + e);
-  const uint2 u = *(const uint2*)((const bf16_t*)p + e);
-  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
-                     __uint_as_float(u.y & 0xffff0000u));
+  const uint2 u = *(const uint2*)((const h16_t*)p + e);
+  return make_float4(rf_h16_lo(u.x), rf_h16_hi(u.x), rf_h16_lo(u.y), rf_h16_hi(u.y));
 }
 __device__ __forceinline__ void st4(void* p, int dt, int64_t e, float4 v) {
   if (dt == RF_F32) {
     *(float4*)((float*)p + e) = v;
   } else {
     uint2 w;
-    w.x = rf_pack2_bf16(v.x, v.y);
-    w.y = rf_pack2_bf16(v.z, v.w);
-    *(uint2*)((bf16_t*)p + e) = w;
+    w.x = rf_pack2_h16(v.x, v.y);
+    w.y = rf_pack2_h16(v.z, v.w);
+    *(uint2*)((h16_t*)p + e) = w;
   }
 }
 
@@ -159,9 +158,9 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int6
             *(float4*)((float*)y + row * y_ld + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
           } else {
             uint2 w;
-            w.x = rf_pack2_bf16(o[0], o[1]);
-            w.y = rf_pack2_bf16(o[2], o[3]);
-            *(uint2*)((bf16_t*)y + row * y_ld + 4 * c) = w;
+            w.x = rf_pack2_h16(o[0], o[1]);
+            w.y = rf_pack2_h16(o[2], o[3]);
+            *(uint2*)((h16_t*)y + row * y_ld + 4 * c) = w;
           }
         }
       }
@@ -243,9 +242,9 @@ __global__ __launch_bounds__(256) void layernorm_rows8_kernel(const float* x, in
         *(float4*)((float*)y + row * y_ld + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
       } else {
         uint2 w;
-        w.x = rf_pack2_bf16(o[0], o[1]);
-        w.y = rf_pack2_bf16(o[2], o[3]);
-        *(uint2*)((bf16_t*)y + row * y_ld + 4 * c) = w;
+        w.x = rf_pack2_h16(o[0], o[1]);
+        w.y = rf_pack2_h16(o[2], o[3]);
+        *(uint2*)((h16_t*)y + row * y_ld + 4 * c) = w;
       }
     }
   }
@@ -253,7 +252,7 @@ __global__ __launch_bounds__(256) void layernorm_rows8_kernel(const float* x, in
 
 // bf16-input twin (the 1024-wide outer-product rows, rf.py:416): 16-byte loads of 8 bf16, NCH chunks per lane
 template <int NCH>
-__global__ __launch_bounds__(256) void layernorm_vec_bf16_kernel(const bf16_t* x, int64_t x_ld, void* y, int y_dt, int64_t y_ld,
+__global__ __launch_bounds__(256) void layernorm_vec_bf16_kernel(const h16_t* x, int64_t x_ld, void* y, int y_dt, int64_t y_ld,
                                                                  int64_t rows, int D, const float* gamma, const float* beta,
                                                                  float eps) {
   const int lane = threadIdx.x & 63;
@@ -271,8 +270,8 @@ __global__ __launch_bounds__(256) void layernorm_vec_bf16_kernel(const bf16_t* x
       const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        v[t][2 * e] = __uint_as_float(w[e] << 16);
-        v[t][2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u);
+        v[t][2 * e] = rf_h16_lo(w[e]);
+        v[t][2 * e + 1] = rf_h16_hi(w[e]);
         s += v[t][2 * e] + v[t][2 * e + 1];
       }
     }
@@ -307,11 +306,11 @@ __global__ __launch_bounds__(256) void layernorm_vec_bf16_kernel(const bf16_t* x
           *(float4*)(yp + 4) = make_float4(o[4], o[5], o[6], o[7]);
         } else {
           uint4 w;
-          w.x = rf_pack2_bf16(o[0], o[1]);
-          w.y = rf_pack2_bf16(o[2], o[3]);
-          w.z = rf_pack2_bf16(o[4], o[5]);
-          w.w = rf_pack2_bf16(o[6], o[7]);
-          *(uint4*)((bf16_t*)y + row * y_ld + 8 * c) = w;
+          w.x = rf_pack2_h16(o[0], o[1]);
+          w.y = rf_pack2_h16(o[2], o[3]);
+          w.z = rf_pack2_h16(o[4], o[5]);
+          w.w = rf_pack2_h16(o[6], o[7]);
+          *(uint4*)((h16_t*)y + row * y_ld + 8 * c) = w;
         }
       }
     }
@@ -361,9 +360,9 @@ __global__ __launch_bounds__(256) void layernorm_narrow_kernel(const float* x, i
         *(float4*)((float*)y + row * y_ld + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
       } else {
         uint2 w;
-        w.x = rf_pack2_bf16(o[0], o[1]);
-        w.y = rf_pack2_bf16(o[2], o[3]);
-        *(uint2*)((bf16_t*)y + row * y_ld + 4 * c) = w;
+        w.x = rf_pack2_h16(o[0], o[1]);
+        w.y = rf_pack2_h16(o[2], o[3]);
+        *(uint2*)((h16_t*)y + row * y_ld + 4 * c) = w;
       }
     }
   }
@@ -404,10 +403,10 @@ static int launch_ln(const void* x, int x_dt, int64_t x_ld, void* y, int y_dt, i
     return rf_launch_status();
   }
   const bool al16 = ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && (!g || (((uintptr_t)g % 16) == 0 && ((uintptr_t)b % 16) == 0));
-  if (!SYM && x_dt == RF_BF16 && groups <= 1 && act == RF_ACT_NONE && D % 8 == 0 && D > 512 && D <= 1024 && x_ld % 8 == 0 &&
+  if (!SYM && x_dt == RF_H16 && groups <= 1 && act == RF_ACT_NONE && D % 8 == 0 && D > 512 && D <= 1024 && x_ld % 8 == 0 &&
       y_ld % 8 == 0 && al16) {
     const unsigned gv = (unsigned)(rows < 8192 ? cdiv(rows, 4) : 2048);
-    hipLaunchKernelGGL((layernorm_vec_bf16_kernel<2>), dim3(gv), dim3(256), 0, s, (const bf16_t*)x, x_ld, y, y_dt, y_ld, rows, D, g, b, eps);
+    hipLaunchKernelGGL((layernorm_vec_bf16_kernel<2>), dim3(gv), dim3(256), 0, s, (const h16_t*)x, x_ld, y, y_dt, y_ld, rows, D, g, b, eps);
     return rf_launch_status();
   }
   if (!SYM && x_dt == RF_F32 && (D == 32 || D == 64) && x_ld % 4 == 0 && y_ld % 4 == 0 && al16) {
@@ -545,24 +544,33 @@ __global__ __launch_bounds__(256) void poswise_kernel(const void* q0, int q0_dt,
     const int64_t kb = (((int64_t)b * N + n) * L + l) * k_ld + k_col0 + h * k_hs;
     const int64_t qb = ((int64_t)b * L + l) * q0_ld + h * dlen;
     float a = 0.f;
-    if (dt == RF_BF16 && q0_dt == RF_BF16 && (dlen & 7) == 0 && ((kb | qb) & 7) == 0) {
-      const bf16x8* qp = (const bf16x8*)((const bf16_t*)q0 + qb);
-      const bf16x8* kp = (const bf16x8*)((const bf16_t*)k + kb);
+    if (dt == RF_H16 && q0_dt == RF_H16 && (dlen & 7) == 0 && ((kb | qb) & 7) == 0) {
+      const h16x8* qp = (const h16x8*)((const h16_t*)q0 + qb);
+      const h16x8* kp = (const h16x8*)((const h16_t*)k + kb);
       for (int c = 0; c < (dlen >> 3); ++c) {
-        const bf16x8 qv = qp[c], kv = kp[c];
+        const h16x8 qv = qp[c], kv = kp[c];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a = fmaf(bf2f((bf16_t)qv[e]), bf2f((bf16_t)kv[e]), a);
+        for (int e = 0; e < 8; ++e) a = fmaf(h2f((h16_t)qv[e]), h2f((h16_t)kv[e]), a);
       }
-    } else if (dt == RF_BF16 && q0_dt == RF_F32 && (dlen & 7) == 0 && (kb & 7) == 0 && (qb & 3) == 0) {
+    } else if (dt == RF_H16 && q0_dt == RF_F32 && (dlen & 7) == 0 && (kb & 7) == 0 && (qb & 3) == 0) {
       const float4* qp = (const float4*)((const float*)q0 + qb);
-      const bf16x8* kp = (const bf16x8*)((const bf16_t*)k + kb);
+      const h16x8* kp = (const h16x8*)((const h16_t*)k + kb);
       for (int c = 0; c < (dlen >> 3); ++c) {
-        const bf16x8 kv = kp[c];
+        const h16x8 kv = kp[c];
         const float4 q1 = qp[2 * c], q2 = qp[2 * c + 1];
-        a = fmaf(q1.x, bf2f((bf16_t)kv[0]), a); a = fmaf(q1.y, bf2f((bf16_t)kv[1]), a);
-        a = fmaf(q1.z, bf2f((bf16_t)kv[2]), a); a = fmaf(q1.w, bf2f((bf16_t)kv[3]), a);
-        a = fmaf(q2.x, bf2f((bf16_t)kv[4]), a); a = fmaf(q2.y, bf2f((bf16_t)kv[5]), a);
-        a = fmaf(q2.z, bf2f((bf16_t)kv[6]), a); a = fmaf(q2.w, bf2f((bf16_t)kv[7]), a);
+        a = fmaf(q1.x, h2f((h16_t)kv[0]), a); a = fmaf(q1.y, h2f((h16_t)kv[1]), a);
+        a = fmaf(q1.z, h2f((h16_t)kv[2]), a); a = fmaf(q1.w, h2f((h16_t)kv[3]), a);
+        a = fmaf(q2.x, h2f((h16_t)kv[4]), a); a = fmaf(q2.y, h2f((h16_t)kv[5]), a);
+        a = fmaf(q2.z, h2f((h16_t)kv[6]), a); a = fmaf(q2.w, h2f((h16_t)kv[7]), a);
+      }
+    } else if (dt == RF_F32 && q0_dt == RF_F32 && (dlen & 3) == 0 && ((kb | qb) & 3) == 0) {
+      // fp32 x fp32 (structure-track node input: LayerNorm(msa) is kept in fp32 there), same c-ordered fmaf chain as below
+      const float4* qp = (const float4*)((const float*)q0 + qb);
+      const float4* kp = (const float4*)((const float*)k + kb);
+      for (int c = 0; c < (dlen >> 2); ++c) {
+        const float4 q1 = qp[c], k1 = kp[c];
+        a = fmaf(q1.x, k1.x, a); a = fmaf(q1.y, k1.y, a);
+        a = fmaf(q1.z, k1.z, a); a = fmaf(q1.w, k1.w, a);
       }
     } else {
       for (int c = 0; c < dlen; ++c) a = fmaf(ld(q0, q0_dt, qb + c), ld(k, dt, kb + c), a);
@@ -588,12 +596,12 @@ __global__ __launch_bounds__(256) void poswise_kernel(const void* q0, int q0_dt,
     if (qs) {
       const int64_t o = (((int64_t)b * N + n) * L + l) * qs_ld + qs_col0 + h * qs_dh;
       const float f = wv_ * qscale;
-      if (dt == RF_BF16 && (qs_dh & 7) == 0 && (o & 7) == 0) {
-        bf16x8* qp = (bf16x8*)((bf16_t*)qs + o);
+      if (dt == RF_H16 && (qs_dh & 7) == 0 && (o & 7) == 0) {
+        h16x8* qp = (h16x8*)((h16_t*)qs + o);
         for (int c = 0; c < (qs_dh >> 3); ++c) {
-          bf16x8 v = qp[c];
+          h16x8 v = qp[c];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) * f);
+          for (int e = 0; e < 8; ++e) v[e] = (short)f2h(h2f((h16_t)v[e]) * f);
           qp[c] = v;
         }
       } else {
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const void* x, int 
 
 // ---- vectorised fast paths (x bf16 NHWC, C % 8 == 0): 16-byte loads, 8 channels per thread -------------------
 #define INV_PIX 512  // pixels per block in the vectorised statistics kernel
-__global__ __launch_bounds__(256) void instnorm_stats_vec_kernel(const bf16_t* x, double* sums, float* partials, int64_t HW,
+__global__ __launch_bounds__(256) void instnorm_stats_vec_kernel(const h16_t* x, double* sums, float* partials, int64_t HW,
                                                                  int C) {
   extern __shared__ float sm[];  // [ppi][2][C]: one slot per pixel group, summed in a fixed order (run-to-run identical)
   const int b = blockIdx.y;
@@ -674,18 +682,18 @@ __global__ __launch_bounds__(256) void instnorm_stats_vec_kernel(const bf16_t* x
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
     // 8 independent 16-byte loads in flight per thread (one load per iteration left the kernel latency-bound at 1.7 TB/s)
     for (int64_t p = p0 + po; p < p1; p += 8 * ppi) {
-      bf16x8 v[8];
+      h16x8 v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int64_t pp = p + (int64_t)u * ppi;
-        v[u] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (pp < p1) v[u] = *(const bf16x8*)(x + ((int64_t)b * HW + pp) * C + ch * 8);
+        v[u] = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (pp < p1) v[u] = *(const h16x8*)(x + ((int64_t)b * HW + pp) * C + ch * 8);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float f = bf2f((bf16_t)v[u][e]);
+          const float f = h2f((h16_t)v[u][e]);
           s[e] += f;
           q[e] = fmaf(f, f, q[e]);
         }
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const float* par
   }
 }
 
-__global__ __launch_bounds__(256) void instnorm_apply_vec_kernel(const bf16_t* x, const double* sums, const float* gamma,
+__global__ __launch_bounds__(256) void instnorm_apply_vec_kernel(const h16_t* x, const double* sums, const float* gamma,
                                                                  const float* beta, float eps, const float* residual,
                                                                  int act, void* y, int y_dt, void* y2, int y2_dt,
                                                                  int64_t HW, int C) {
@@ -745,10 +753,10 @@ __global__ __launch_bounds__(256) void instnorm_apply_vec_kernel(const bf16_t* x
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nchunks; idx += (int64_t)gridDim.x * 256) {
     const int ch = idx % nch;
     const int64_t e0 = ((int64_t)b * HW) * C + idx * 8;  // idx = pixel*nch + ch -> element offset pixel*C + ch*8
-    const bf16x8 v = *(const bf16x8*)(x + e0);
+    const h16x8 v = *(const h16x8*)(x + e0);
     float o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = bf2f((bf16_t)v[e]) * sm[ch * 8 + e] + sm[C + ch * 8 + e];
+    for (int e = 0; e < 8; ++e) o[e] = h2f((h16_t)v[e]) * sm[ch * 8 + e] + sm[C + ch * 8 + e];
     if (residual) {
       const float4 r0 = *(const float4*)(residual + e0), r1 = *(const float4*)(residual + e0 + 4);
       o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w;
@@ -764,11 +772,11 @@ __global__ __launch_bounds__(256) void instnorm_apply_vec_kernel(const bf16_t* x
         *(float4*)((float*)dst + e0 + 4) = make_float4(o[4], o[5], o[6], o[7]);
       } else {
         uint4 w;
-        w.x = rf_pack2_bf16(o[0], o[1]);
-        w.y = rf_pack2_bf16(o[2], o[3]);
-        w.z = rf_pack2_bf16(o[4], o[5]);
-        w.w = rf_pack2_bf16(o[6], o[7]);
-        *(uint4*)((bf16_t*)dst + e0) = w;
+        w.x = rf_pack2_h16(o[0], o[1]);
+        w.y = rf_pack2_h16(o[2], o[3]);
+        w.z = rf_pack2_h16(o[4], o[5]);
+        w.w = rf_pack2_h16(o[6], o[7]);
+        *(uint4*)((h16_t*)dst + e0) = w;
       }
     };
     put(y, y_dt);
@@ -788,11 +796,11 @@ extern "C" int rf_instnorm_stats(const void* x, int x_dtype, void* sums, int B, 
   // bitwise reproducible run to run
   if (!workspace || ws_bytes < rf_instnorm_ws_bytes(B, HW, C)) return RF_EINVAL;
   float* partials = (float*)workspace;
-  if (x_dtype == RF_BF16 && C % 8 == 0 && C / 8 <= 256 && ((uintptr_t)x % 16) == 0) {
+  if (x_dtype == RF_H16 && C % 8 == 0 && C / 8 <= 256 && ((uintptr_t)x % 16) == 0) {
     const unsigned nblk = cdiv(HW, INV_PIX);
     const int ppi = 256 / (C / 8);
     hipLaunchKernelGGL(instnorm_stats_vec_kernel, dim3(nblk, B), dim3(256), (size_t)ppi * 2 * C * sizeof(float),
-                       (hipStream_t)stream, (const bf16_t*)x, (double*)sums, partials, HW, C);
+                       (hipStream_t)stream, (const h16_t*)x, (double*)sums, partials, HW, C);
     hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(cdiv(2 * C, 32), B), dim3(256), 0, (hipStream_t)stream, partials,
                        (double*)sums, (int)nblk, C);
     return rf_launch_status();
@@ -831,11 +839,11 @@ extern "C" int rf_instnorm_apply(const void* x, int x_dtype, const void* sums, c
   RF_CHECK_DT(x_dtype);
   RF_CHECK_DT(y_dtype);
   const int64_t total = (int64_t)B * HW * C;
-  if (x_dtype == RF_BF16 && C % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+  if (x_dtype == RF_H16 && C % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
       (!y2 || ((uintptr_t)y2 % 16) == 0) && (!residual || ((uintptr_t)residual % 16) == 0)) {
     const unsigned gx = min(cdiv(HW * (C / 8), 256), 4096u);
     hipLaunchKernelGGL(instnorm_apply_vec_kernel, dim3(gx, B), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
-                       (const bf16_t*)x, (const double*)sums, gamma, beta, eps, residual, act, y, y_dtype, y2, y2_dtype,
+                       (const h16_t*)x, (const double*)sums, gamma, beta, eps, residual, act, y, y_dtype, y2, y2_dtype,
                        HW, C);
     return rf_launch_status();
   }
@@ -1235,11 +1243,11 @@ __global__ __launch_bounds__(256) void fill_kernel(void* y, int dt, float v, int
     for (int64_t e = t0; e < n4; e += stride) y4[e] = make_float4(v, v, v, v);
     for (int64_t e = (n4 << 2) + t0; e < n; e += stride) ((float*)y)[e] = v;
   } else {
-    const unsigned h = f2bf(v), w = h | (h << 16);
+    const unsigned h = f2h(v), w = h | (h << 16);
     uint4* y8 = (uint4*)y;
     const int64_t n8 = n >> 3;
     for (int64_t e = t0; e < n8; e += stride) y8[e] = make_uint4(w, w, w, w);
-    for (int64_t e = (n8 << 3) + t0; e < n; e += stride) ((bf16_t*)y)[e] = (bf16_t)h;
+    for (int64_t e = (n8 << 3) + t0; e < n; e += stride) ((h16_t*)y)[e] = (h16_t)h;
   }
 }
 
@@ -1354,5 +1362,11 @@ extern "C" int rf_add_pos_enc(const float* x, const int64_t* aa_idx, const float
   return rf_launch_status();
 }
 
-extern "C" int rf_version(void) { return 3; }
-extern "C" const char* rf_build_info(void) { return "librfmi gfx950 (MI355X) round-2"; }
+extern "C" int rf_version(void) { return 4; }
+#ifdef RF_H16_IS_F16
+extern "C" const char* rf_build_info(void) { return "librfmi_f16 gfx950 (MI355X) round-3: 16-bit operand type = IEEE fp16"; }
+#else
+extern "C" const char* rf_build_info(void) { return "librfmi gfx950 (MI355X) round-3: 16-bit operand type = bfloat16"; }
+#endif
+// the dtype code this build accepts for 16-bit tensors (RF_BF16 in librfmi.so, RF_F16 in librfmi_f16.so)
+extern "C" int rf_h16_dtype(void) { return RF_H16; }

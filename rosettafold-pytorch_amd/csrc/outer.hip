@@ -22,9 +22,9 @@
 static __device__ __attribute__((aligned(16))) unsigned int g_outer_zero16[4];
 
 struct OuterP {
-  const bf16_t* xt;   // [B, L, 32, N]   x_t[b,i,u,n]  (MSA depth contiguous)
-  const bf16_t* yt;   // [B, L, 32, N]
-  const bf16_t* wp;   // [Dout, 1024]    W * gamma
+  const h16_t* xt;   // [B, L, 32, N]   x_t[b,i,u,n]  (MSA depth contiguous)
+  const h16_t* yt;   // [B, L, 32, N]
+  const h16_t* wp;   // [Dout, 1024]    W * gamma
   const float* s;     // [Dout]          row sums of wp
   const float* c;     // [Dout]          W beta + bias
   float* out;         // [B, L, L, Dout] fp32
@@ -35,7 +35,7 @@ struct OuterP {
   const float* g2;
   const float* b2;
   float eps2;
-  bf16_t* y;
+  h16_t* y;
   int64_t y_ld;
   int ntiles;
   int dbg;  // timing experiments only (RF_OUTER_DBG; results are wrong when set): 1 skip stage 1, 2 skip stage 2, 4 skip the W'
@@ -46,7 +46,7 @@ __device__ __forceinline__ void outer_glds16(const void* src, void* lds_wave_bas
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-__device__ __forceinline__ unsigned outer_pack2(float a, float b) { return rf_pack2_bf16(a, b); }
+__device__ __forceinline__ unsigned outer_pack2(float a, float b) { return rf_pack2_h16(a, b); }
 // workgroup barrier that publishes this wave's LDS writes but leaves its DMAs in flight (a __syncthreads() would drain them)
 __device__ __forceinline__ void outer_lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(576) void outer_fused_kernel(const OuterP p) {
 
   // stage-2 constants of this wave: columns o = 32 wave + 16 c + 4 fq .. +3
   const int o_w = wave * 32;
-  const bf16_t* const wrow = p.wp + (int64_t)(o_w + fr) * 1024 + fq * 32;  // + cc * 16 rows + (8 ug + 4 s2) * 32 + 8 vg
+  const h16_t* const wrow = p.wp + (int64_t)(o_w + fr) * 1024 + fq * 32;  // + cc * 16 rows + (8 ug + 4 s2) * 32 + 8 vg
 
   // stage-1 geometry of this wave (waves 0-7): y row tile art (rows = (j, v)), x column tiles bct0 .. bct0 + 3 (cols = (i, u))
   const int art = wave & 3, bct0 = (wave >> 2) * 4;
@@ -97,12 +97,25 @@ __global__ __launch_bounds__(576) void outer_fused_kernel(const OuterP p) {
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) a2r[s2] = fr * 128 + (((4 * s2 + fq) ^ ((fr >> 1) & 7)) << 4);  // (+ rt * 2048: (16 rt + fr) >> 1 & 7 == (fr >> 1) & 7)
 
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  // XCD-aware tile walk.  Workgroups b and b + 8 share an XCD (and its 4 MB L2); the tile sequence (b, i tile, j tile; j
+  // fastest) is cut into 8 contiguous ranges, one per XCD group, and the workgroups of a group walk their range side by
+  // side: the tiles in flight on one XCD share their 128 KB x rows (same i tile) and the 64 KB y rows of a j tile come
+  // back from L2 for every later i tile of the range.  (Round 2 walked `tile = blockIdx.x + k * gridDim.x`: the 8
+  // workgroups sharing an i tile sat on 8 different L2s and x / y were fetched ~20 times over, 328 MB per launch.)
+  int t_begin = blockIdx.x, t_end = p.ntiles, t_step = gridDim.x;
+  if (gridDim.x >= 8) {
+    const int x = blockIdx.x & 7, q = p.ntiles >> 3, r = p.ntiles & 7;
+    const int lo = x * q + (x < r ? x : r);
+    t_end = lo + q + (x < r ? 1 : 0);
+    t_step = ((int)gridDim.x - x + 7) >> 3;  // workgroups in this group
+    t_begin = lo + (int)(blockIdx.x >> 3);
+  }
+  for (int tile = t_begin; tile < t_end; tile += t_step) {
     const int jt = tile % (p.L / TJ), t2 = tile / (p.L / TJ);
     const int it = t2 % (p.L / TI), b = t2 / (p.L / TI);
     const int i0 = it * TI, j0 = jt * TJ;
-    const bf16_t* xb = p.xt + ((int64_t)b * p.L + i0) * 32 * N;
-    const bf16_t* yb = p.yt + ((int64_t)b * p.L + j0) * 32 * N;
+    const h16_t* xb = p.xt + ((int64_t)b * p.L + i0) * 32 * N;
+    const h16_t* yb = p.yt + ((int64_t)b * p.L + j0) * 32 * N;
 
     // (every wave issues exactly PDX / PDY DMA instructions per call -- padded with dummies -- so the waits can be counted)
     auto dma_x = [&](int ug) {  // rows (i_l, u_l): i_l = row >> 3, u = 8 ug + (row & 7)
@@ -111,7 +124,7 @@ __global__ __launch_bounds__(576) void outer_fused_kernel(const OuterP p) {
       for (int t = 0; t < PDX; ++t) {
         const int q = wave + 9 * t;
         const int row = q * RPI + lane / SPR, sl = lane % SPR;
-        const bf16_t* src = xb + ((int64_t)(row >> 3) * 32 + ug * 8 + (row & 7)) * N + ((sl ^ (swz(row) & (SPR - 1))) << 3);
+        const h16_t* src = xb + ((int64_t)(row >> 3) * 32 + ug * 8 + (row & 7)) * N + ((sl ^ (swz(row) & (SPR - 1))) << 3);
         if (q < XI)
           outer_glds16(src, dst + q * 1024);
         else
@@ -125,7 +138,7 @@ __global__ __launch_bounds__(576) void outer_fused_kernel(const OuterP p) {
       for (int t = 0; t < PDY; ++t) {
         const int q = wave + 9 * t;
         const int row = q * RPI + lane / SPR, sl = lane % SPR;
-        const bf16_t* src = yb + ((int64_t)(row >> 3) * 32 + vg * 8 + (row & 7)) * N + ((sl ^ (swz(row) & (SPR - 1))) << 3);
+        const h16_t* src = yb + ((int64_t)(row >> 3) * 32 + vg * 8 + (row & 7)) * N + ((sl ^ (swz(row) & (SPR - 1))) << 3);
         if (q < YI)
           outer_glds16(src, dst + q * 1024);
         else
@@ -142,9 +155,9 @@ __global__ __launch_bounds__(576) void outer_fused_kernel(const OuterP p) {
 
     // W' fragments (L2 -> registers) run one chunk ahead WITHOUT a second register set: the fragments of K step s2 of chunk
     // c + 1 are loaded into the registers of step s2 of chunk c as soon as that step's MFMAs have been issued.
-    bf16x8 wf0[2], wf1[2];
+    h16x8 wf0[2], wf1[2];
     auto wload = [&](int c, int s2, int cc) {
-      return *(const bf16x8*)(wrow + cc * 16 * 1024 + (8 * (c >> 2) + 4 * s2) * 32 + 8 * (c & 3));
+      return *(const h16x8*)(wrow + cc * 16 * 1024 + (8 * (c >> 2) + 4 * s2) * 32 + 8 * (c & 3));
     };
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
@@ -163,11 +176,11 @@ __global__ __launch_bounds__(576) void outer_fused_kernel(const OuterP p) {
 #pragma unroll
       for (int s = 0; s < NKS; ++s) {
         const int sl = ((4 * s + fq) ^ fsw) << 4;
-        const bf16x8 yf = *(const bf16x8*)(ys + y_rd + sl);
+        const h16x8 yf = *(const h16x8*)(ys + y_rd + sl);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const bf16x8 xf = *(const bf16x8*)(xs + x_rd0 + t * 16 * NB + sl);
-          d[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf, xf, d[t], 0, 0, 0);  // lane: (j,v) = 4 fq + r, (i,u) = fr
+          const h16x8 xf = *(const h16x8*)(xs + x_rd0 + t * 16 * NB + sl);
+          d[t] = rf_mfma16(yf, xf, d[t], 0, 0, 0);  // lane: (j,v) = 4 fq + r, (i,u) = fr
         }
       }
       // (LDS store through inline asm: hipcc puts s_waitcnt vmcnt(0) in front of a visible ds_write while LDS-DMAs are in
@@ -186,19 +199,19 @@ __global__ __launch_bounds__(576) void outer_fused_kernel(const OuterP p) {
     };
     // one K step (32 features) of stage 2 of chunk c: out[pair, o] += A2[pair, chunk] . W'[o, chunk]
     // W' tile as MFMA-A, chunk image as MFMA-B: lane holds out[pair = 16 rt + fr][o = 32 w + 16 cc + 4 fq .. +3]
-    auto stage2 = [&](int c, int s2, const bf16x8 (&wf)[2]) {
+    auto stage2 = [&](int c, int s2, const h16x8 (&wf)[2]) {
       if (p.dbg & 2) return;
       const char* a2 = smem + A2_OFF + (c & 1) * A2B;
 #pragma unroll
       for (int r0 = 0; r0 < 8; r0 += 4) {  // four image fragments in flight per batch of eight MFMAs
-        bf16x8 af[4];
+        h16x8 af[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) af[k] = *(const bf16x8*)(a2 + (r0 + k) * 2048 + a2r[s2]);
+        for (int k = 0; k < 4; ++k) af[k] = *(const h16x8*)(a2 + (r0 + k) * 2048 + a2r[s2]);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
           for (int cc = 0; cc < 2; ++cc)
-            acc[r0 + k][cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cc], af[k], acc[r0 + k][cc], 0, 0, 0);
+            acc[r0 + k][cc] = rf_mfma16(wf[cc], af[k], acc[r0 + k][cc], 0, 0, 0);
       }
     };
 
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(576) void outer_fused_kernel(const OuterP p) {
       for (int rt = 0; rt < 8; ++rt) {
         const int pr = 16 * rt + fr;
         const float2 ms = *(const float2*)(stats + 2 * pr);
-        bf16_t* yrow = p.y + (((int64_t)b * p.L + i0 + (pr >> 3)) * p.L + j0 + (pr & 7)) * p.y_ld + o_w + 4 * fq;
+        h16_t* yrow = p.y + (((int64_t)b * p.L + i0 + (pr >> 3)) * p.L + j0 + (pr & 7)) * p.y_ld + o_w + 4 * fq;
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
           const f32x4 v = (acc[rt][cc] - ms.x) * ms.y * g4[cc] + e4[cc];
@@ -359,11 +372,11 @@ extern "C" int rf_outer_product_ln_linear(const void* xt, const void* yt, const 
       ((uintptr_t)out % 16))
     return RF_EALIGN;
   OuterP p;
-  p.xt = (const bf16_t*)xt; p.yt = (const bf16_t*)yt; p.wp = (const bf16_t*)wprime; p.s = s; p.c = c; p.out = out;
+  p.xt = (const h16_t*)xt; p.yt = (const h16_t*)yt; p.wp = (const h16_t*)wprime; p.s = s; p.c = c; p.out = out;
   p.B = B; p.L = L; p.Dout = Dout; p.eps = eps;
   static const int dbg = getenv("RF_OUTER_DBG") ? atoi(getenv("RF_OUTER_DBG")) : 0;
   p.dbg = dbg;
-  p.g2 = ln2_gamma; p.b2 = ln2_beta; p.eps2 = ln2_eps; p.y = (bf16_t*)y; p.y_ld = y_ld;
+  p.g2 = ln2_gamma; p.b2 = ln2_beta; p.eps2 = ln2_eps; p.y = (h16_t*)y; p.y_ld = y_ld;
   hipStream_t st = (hipStream_t)stream;
   if (y) return N == 128 ? launch_outer<4, true>(p, st) : launch_outer<2, true>(p, st);
   return N == 128 ? launch_outer<4, false>(p, st) : launch_outer<2, false>(p, st);

@@ -21,13 +21,13 @@
 static __device__ __attribute__((aligned(16))) unsigned int g_tied_zero16[4];
 
 union TFrag {
-  bf16x8 v;
+  h16x8 v;
   unsigned u[4];
   uint2 h[2];
 };
 typedef __attribute__((ext_vector_type(4))) short ts16x4;
 
-__device__ __forceinline__ unsigned tpack2(float a, float b) { return rf_pack2_bf16(a, b); }
+__device__ __forceinline__ unsigned tpack2(float a, float b) { return rf_pack2_h16(a, b); }
 
 __device__ __forceinline__ void tied_glds16(const void* src, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -38,13 +38,13 @@ __device__ __forceinline__ void tied_glds16(const void* src, void* lds_wave_base
 // logits + softmax
 // ------------------------------------------------------------------------------------------------------------------
 struct TiedP {
-  const bf16_t* q;
-  const bf16_t* k;
+  const h16_t* q;
+  const h16_t* k;
   int64_t b_stride, n_stride, h_stride, l_stride;  // elements (q and k share them); head slice = 32 contiguous elements
   const float* w;                                   // position weights [.., l] or null (q used as it is)
   int64_t w_b, w_h, w_n;                            // element strides of w (l contiguous)
   float qscale;                                     // multiplies w (d_head^-0.5, rf.py:252)
-  bf16_t* att;                                      // [B, H, L, L]
+  h16_t* att;                                      // [B, H, L, L]
   int B, H, N;
   int dbg;  // timing experiments (RF_TIED_DBG; results are WRONG when set): 1 no DMA after the prologue, 2 fragments read once, 4 no MFMA
 };
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(256) void tied_logits_kernel(const TiedP p) {
   }
   constexpr int IT = L / 64;
   const int it = lid % IT, h = (lid / IT) % p.H, b = lid / (IT * p.H);
-  const bf16_t* qb = p.q + (int64_t)b * p.b_stride + (int64_t)h * p.h_stride + (int64_t)(it * 64) * p.l_stride;
-  const bf16_t* kb = p.k + (int64_t)b * p.b_stride + (int64_t)h * p.h_stride;
+  const h16_t* qb = p.q + (int64_t)b * p.b_stride + (int64_t)h * p.h_stride + (int64_t)(it * 64) * p.l_stride;
+  const h16_t* kb = p.k + (int64_t)b * p.b_stride + (int64_t)h * p.h_stride;
 
   // DMA: an instruction covers 16 rows x 4 chunks (64-byte head slices); lane-linear LDS image with the bank swizzle
   // chunk ^ g((row >> 2) & 3), g = {0, 2, 3, 1}, on the source chunk and on the fragment reads
@@ -120,23 +120,23 @@ __global__ __launch_bounds__(256) void tied_logits_kernel(const TiedP p) {
     stage(n + NSTG - 1);  // into the buffer of step n-1, whose fragments every wave has consumed
     const char* st = smem + (n % NSTG) * STAGE;
     TFrag qf;
-    bf16x8 kf[JT];
+    h16x8 kf[JT];
     if (!(p.dbg & 2) || n == 0) {
-      qf.v = *(const bf16x8*)(st + q_rd);
+      qf.v = *(const h16x8*)(st + q_rd);
 #pragma unroll
-      for (int j = 0; j < JT; ++j) kf[j] = *(const bf16x8*)(st + k_rd + j * 1024);
+      for (int j = 0; j < JT; ++j) kf[j] = *(const h16x8*)(st + k_rd + j * 1024);
     }
     if constexpr (SCALE) {
       const float ws = wrow[n * 64] * p.qscale;  // w[b,h,n, row of this lane] * d_head^-0.5: the same rounding point as q*w (rf.py:252)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        qf.u[e] = tpack2(__uint_as_float(qf.u[e] << 16) * ws, __uint_as_float(qf.u[e] & 0xffff0000u) * ws);
+        qf.u[e] = tpack2(rf_h16_lo(qf.u[e]) * ws, rf_h16_hi(qf.u[e]) * ws);
     }
     if (!(p.dbg & 4)) {
 #pragma unroll
       for (int j = 0; j < JT; ++j)
         // key tile as MFMA-A, query tile as MFMA-B: lane holds logits[i = fr][j = 16*tile + 4*fq .. +3]
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[j], qf.v, acc[j], 0, 0, 0);
+        acc[j] = rf_mfma16(kf[j], qf.v, acc[j], 0, 0, 0);
     }
   }
 
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void tied_logits_kernel(const TiedP p) {
   }
   asm volatile("" ::: "memory");
   constexpr int CPR = L * 2 / 16, NCH = 16 * CPR, NIT = NCH / 64;
-  bf16_t* arow = p.att + (((int64_t)b * p.H + h) * L + it * 64 + wave * 16) * L;
+  h16_t* arow = p.att + (((int64_t)b * p.H + h) * L + it * 64 + wave * 16) * L;
 #pragma unroll
   for (int t = 0; t < NIT; ++t) {
     const int idx = lane + 64 * t;
@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256) void tied_logits_kernel(const TiedP p) {
 // ------------------------------------------------------------------------------------------------------------------
 #define TIED_SPLIT_NSTG 5  // ring stages of 24 KB: the stream is latency-bound (~2 us per piece under load), bytes in flight = rate
 struct TiedSplitP {
-  const bf16_t* q;
-  const bf16_t* k;
+  const h16_t* q;
+  const h16_t* k;
   int64_t b_stride, n_stride, h_stride, l_stride;
   const float* w;
   int64_t w_b, w_h, w_n;
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(512) void tied_logits_split_kernel(const TiedSplitP
   const int rb = lid & 1, sp = (lid >> 1) % p.nsplit;
   const int bh = lid / (2 * p.nsplit), h = bh % p.H, b = bh / p.H;
   const int n0 = sp * p.nper;
-  const bf16_t* qb = p.q + (int64_t)b * p.b_stride + (int64_t)h * p.h_stride + (int64_t)(rb * RB) * p.l_stride;
-  const bf16_t* kb = p.k + (int64_t)b * p.b_stride + (int64_t)h * p.h_stride;
+  const h16_t* qb = p.q + (int64_t)b * p.b_stride + (int64_t)h * p.h_stride + (int64_t)(rb * RB) * p.l_stride;
+  const h16_t* kb = p.k + (int64_t)b * p.b_stride + (int64_t)h * p.h_stride;
 
   const int lrow = lane >> 2;
   const int c_log = (lane & 3) ^ ((0x78 >> (((lrow >> 2) & 3) * 2)) & 3);
@@ -275,12 +275,12 @@ __global__ __launch_bounds__(512) void tied_logits_split_kernel(const TiedSplitP
     stage(t_ + NSTG - 1);  // into the buffer of step t_ - 1, whose fragments every wave has consumed
     const char* st = smem + (t_ % NSTG) * STAGE;
     TFrag qf[4];
-    bf16x8 kf[4];
+    h16x8 kf[4];
     if (!(p.dbg & 2) || t_ == 0) {
 #pragma unroll
-      for (int qt = 0; qt < 4; ++qt) qf[qt].v = *(const bf16x8*)(st + q_rd + qt * 1024);
+      for (int qt = 0; qt < 4; ++qt) qf[qt].v = *(const h16x8*)(st + q_rd + qt * 1024);
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt) kf[kt] = *(const bf16x8*)(st + k_rd + kt * 1024);
+      for (int kt = 0; kt < 4; ++kt) kf[kt] = *(const h16x8*)(st + k_rd + kt * 1024);
     }
     if constexpr (SCALE) {
 #pragma unroll
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512) void tied_logits_split_kernel(const TiedSplitP
         const float ws = wrow[t_ * RB + qt * 16] * p.qscale;  // w[b,h,n, query row of this lane] * d_head^-0.5 (rf.py:252)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          qf[qt].u[e] = tpack2(__uint_as_float(qf[qt].u[e] << 16) * ws, __uint_as_float(qf[qt].u[e] & 0xffff0000u) * ws);
+          qf[qt].u[e] = tpack2(rf_h16_lo(qf[qt].u[e]) * ws, rf_h16_hi(qf[qt].u[e]) * ws);
       }
     }
     if (!(p.dbg & 4)) {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(512) void tied_logits_split_kernel(const TiedSplitP
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt)
           // key tile as MFMA-A, query tile as MFMA-B: lane holds logits[i = 16 qt + fr][j = 16 kt + 4 fq .. +3]
-          acc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt].v, acc[kt][qt], 0, 0, 0);
+          acc[kt][qt] = rf_mfma16(kf[kt], qf[qt].v, acc[kt][qt], 0, 0, 0);
     }
   }
   if (p.dbg & 8) return;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(512) void tied_logits_split_kernel(const TiedSplitP
 
 // att[row, :] = softmax(sum_s part[s][row, :]) for L = 256: one wave per row, 4 columns per lane
 __global__ __launch_bounds__(256) void tied_split_softmax_kernel(const float* part, int64_t split_stride, int nsplit,
-                                                                 bf16_t* att, int64_t rows) {
+                                                                 h16_t* att, int64_t rows) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256) void tied_split_softmax_kernel(const float* pa
   *(uint2*)(att + row * 256 + lane * 4) = o;
 }
 
-__global__ __launch_bounds__(256) void tied_att_sym_kernel(const bf16_t* att, float* sym, int64_t sym_ld, int B, int H, int L) {
+__global__ __launch_bounds__(256) void tied_att_sym_kernel(const h16_t* att, float* sym, int64_t sym_ld, int B, int H, int L) {
   // sym[b,i,j,h] = 0.5*(att[b,h,i,j] + att[b,h,j,i])
   const int64_t n = (int64_t)B * L * L * H;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void tied_att_sym_kernel(const bf16_t* att, fl
     const int j = t % L, i = (t / L) % L;
     const int64_t b = t / ((int64_t)L * L);
     const int64_t o = (b * H + h) * L;
-    sym[t * sym_ld + h] = 0.5f * (bf2f(att[(o + i) * L + j]) + bf2f(att[(o + j) * L + i]));
+    sym[t * sym_ld + h] = 0.5f * (h2f(att[(o + i) * L + j]) + h2f(att[(o + j) * L + i]));
   }
 }
 
@@ -407,7 +407,7 @@ static int tied_sym(const void* att, float* att_sym, int64_t sym_ld, int B, int 
   const int64_t n = (int64_t)B * L * L * H;
   unsigned g = (unsigned)((n + 255) / 256);
   if (g > 8192u) g = 8192u;
-  hipLaunchKernelGGL(tied_att_sym_kernel, dim3(g), dim3(256), 0, s, (const bf16_t*)att, att_sym, sym_ld, B, H, L);
+  hipLaunchKernelGGL(tied_att_sym_kernel, dim3(g), dim3(256), 0, s, (const h16_t*)att, att_sym, sym_ld, B, H, L);
   return rf_launch_status();
 }
 
@@ -419,10 +419,10 @@ extern "C" int rf_tied_logits_softmax(const void* q, const void* k, int64_t b_st
   if (((uintptr_t)q % 16) || ((uintptr_t)k % 16) || ((uintptr_t)att % 16) || b_stride % 8 || n_stride % 8 || l_stride % 8)
     return RF_EALIGN;
   TiedP p;
-  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k;
+  p.q = (const h16_t*)q; p.k = (const h16_t*)k;
   p.b_stride = b_stride; p.n_stride = n_stride; p.l_stride = l_stride; p.h_stride = d_head;
   p.w = nullptr; p.w_b = p.w_h = p.w_n = 0; p.qscale = 1.f;
-  p.att = (bf16_t*)att; p.B = B; p.H = H; p.N = N;
+  p.att = (h16_t*)att; p.B = B; p.H = H; p.N = N;
   p.dbg = tied_dbg();
   hipStream_t s = (hipStream_t)stream;
   const int rc = tied_logits_dispatch(p, L, s);
@@ -436,10 +436,10 @@ extern "C" int rf_tied_logits_softmax(const void* q, const void* k, int64_t b_st
 // through a DMA ring and is consumed with hardware-transposed LDS reads (ds_read_b64_tr_b16).
 // ------------------------------------------------------------------------------------------------------------------
 struct TiedAvP {
-  const bf16_t* att;  // [B, H, L, L]
-  const bf16_t* v;
+  const h16_t* att;  // [B, H, L, L]
+  const h16_t* v;
   int64_t v_b, v_n, v_h, v_l;  // element strides of v (head slice contiguous)
-  bf16_t* out;
+  h16_t* out;
   int64_t o_b, o_n, o_h, o_l;  // element strides of out (head slice contiguous)
   int B, H, N;
   int units_per_wg, nunits;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void tied_av_kernel(const TiedAvP p) {
     char* st = smem + ((u - u0) % NSTG) * STAGE;
     const bool live = u < u1;
     const int n = u % p.N, bh = u / p.N, h = bh % p.H, b = bh / p.H;
-    const bf16_t* vb = p.v + (int64_t)b * p.v_b + (int64_t)n * p.v_n + (int64_t)h * p.v_h;
+    const h16_t* vb = p.v + (int64_t)b * p.v_b + (int64_t)n * p.v_n + (int64_t)h * p.v_h;
 #pragma unroll
     for (int t = 0; t < PW; ++t) {
       const int instr = t * 4 + wave;
@@ -502,13 +502,13 @@ __global__ __launch_bounds__(256, 1) void tied_av_kernel(const TiedAvP p) {
     const int bh = u / p.N;
     const int h = bh % p.H, b = bh / p.H;
     const int uend = (bh + 1) * p.N < u1 ? (bh + 1) * p.N : u1;
-    bf16x8 af[RT][KS];  // att[i = 16 t + fr][32 s + 8 fq .. +7]
+    h16x8 af[RT][KS];  // att[i = 16 t + fr][32 s + 8 fq .. +7]
     {
-      const bf16_t* ab = p.att + ((int64_t)bh * L + wave * (16 * RT)) * L;
+      const h16_t* ab = p.att + ((int64_t)bh * L + wave * (16 * RT)) * L;
 #pragma unroll
       for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) af[t][s] = *(const bf16x8*)(ab + (int64_t)(t * 16 + fr) * L + s * 32 + fq * 8);
+        for (int s = 0; s < KS; ++s) af[t][s] = *(const h16x8*)(ab + (int64_t)(t * 16 + fr) * L + s * 32 + fq * 8);
       // drain here (this also retires every DMA issued so far) and make the fragments opaque, so that the compiler's own
       // wait for these loads sits in front of the unit loop and not inside it
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void tied_av_kernel(const TiedAvP p) {
         vf[1].h[0] = R[2]; vf[1].h[1] = R[3];                                                                    \
         _Pragma("unroll") for (int t = 0; t < RT; ++t) _Pragma("unroll") for (int c = 0; c < 2; ++c)             \
             /* value tile as MFMA-A, probability tile as MFMA-B: lane holds out[i = fr][d = 16 c + 4 fq .. +3] */ \
-            acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[c].v, af[t][S_], acc[t][c], 0, 0, 0);        \
+            acc[t][c] = rf_mfma16(vf[c].v, af[t][S_], acc[t][c], 0, 0, 0);        \
       }
 #define RF_AV_STEP(S_, CUR, NXT)                                    \
       if constexpr (S_ < KS) {                                      \
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256, 1) void tied_av_kernel(const TiedAvP p) {
 #undef RF_AV_ISSUE
       static_assert(KS <= 8, "unrolled key steps");
       const int n = u % p.N;
-      bf16_t* ob = p.out + (int64_t)b * p.o_b + (int64_t)n * p.o_n + (int64_t)h * p.o_h +
+      h16_t* ob = p.out + (int64_t)b * p.o_b + (int64_t)n * p.o_n + (int64_t)h * p.o_h +
                    (int64_t)(wave * 16 * RT + fr) * p.o_l + 4 * fq;
 #pragma unroll
       for (int t = 0; t < RT; ++t)
@@ -600,7 +600,7 @@ extern "C" int rf_tied_av(const void* att, const void* v, const int64_t v_stride
     if (v_strides[i] % 8 || o_strides[i] % 4) return RF_EALIGN;
   if ((int64_t)B * H * N > 0x7fffffffLL) return RF_EINVAL;
   TiedAvP p;
-  p.att = (const bf16_t*)att; p.v = (const bf16_t*)v; p.out = (bf16_t*)out;
+  p.att = (const h16_t*)att; p.v = (const h16_t*)v; p.out = (h16_t*)out;
   p.v_b = v_strides[0]; p.v_n = v_strides[1]; p.v_h = v_strides[2]; p.v_l = v_strides[3];
   p.o_b = o_strides[0]; p.o_n = o_strides[1]; p.o_h = o_strides[2]; p.o_l = o_strides[3];
   p.B = B; p.H = H; p.N = N;
@@ -625,12 +625,12 @@ extern "C" int rf_tied_attention(const void* q, const void* k, const void* v, co
   if (w && (((uintptr_t)w % 16) || w_strides[0] % 4 || w_strides[1] % 4 || w_strides[2] % 4)) return RF_EALIGN;
   if (w && N % 4) return RF_EINVAL;  // the weight tile is staged four MSA rows per DMA instruction
   TiedP p;
-  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k;
+  p.q = (const h16_t*)q; p.k = (const h16_t*)k;
   p.b_stride = qk_strides[0]; p.n_stride = qk_strides[1]; p.h_stride = qk_strides[2]; p.l_stride = qk_strides[3];
   p.w = w;
   p.w_b = w ? w_strides[0] : 0; p.w_h = w ? w_strides[1] : 0; p.w_n = w ? w_strides[2] : 0;
   p.qscale = qscale;
-  p.att = (bf16_t*)att; p.B = B; p.H = H; p.N = N;
+  p.att = (h16_t*)att; p.B = B; p.H = H; p.N = N;
   p.dbg = tied_dbg();
   hipStream_t s = (hipStream_t)stream;
   int rc = tied_logits_split(p, L, partial_ws, partial_ws_elems, s);
@@ -646,27 +646,27 @@ extern "C" int rf_tied_attention(const void* q, const void* k, const void* v, co
 //   w[b,h,n,l] = softmax_n(scale * D[n, h]).
 // ------------------------------------------------------------------------------------------------------------------
 template <int NT>  // NT = N / 16 row tiles
-__global__ __launch_bounds__(256) void poswise_mfma_kernel(const bf16_t* xn, const bf16_t* u, float* w, int B, int N, int L,
+__global__ __launch_bounds__(256) void poswise_mfma_kernel(const h16_t* xn, const h16_t* u, float* w, int B, int N, int L,
                                                            int D, int H, float scale) {
   const int lane = threadIdx.x & 63;
   const int fr = lane & 15, fq = lane >> 4;
   const int64_t bl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (bl >= (int64_t)B * L) return;
   const int b = bl / L, l = bl % L;
-  const bf16_t* xr = xn + ((int64_t)b * N * L + l) * D + fq * 8;                  // + n * L * D + c
-  const bf16_t* ur = u + (bl * H + (fr < H ? fr : H - 1)) * (int64_t)D + fq * 8;  // (lanes >= H: a valid row, results discarded)
+  const h16_t* xr = xn + ((int64_t)b * N * L + l) * D + fq * 8;                  // + n * L * D + c
+  const h16_t* ur = u + (bl * H + (fr < H ? fr : H - 1)) * (int64_t)D + fq * 8;  // (lanes >= H: a valid row, results discarded)
   f32x4 acc[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int c = 0; c < D; c += 32) {
-    const bf16x8 uf = *(const bf16x8*)(ur + c);
-    bf16x8 xf[NT];
+    const h16x8 uf = *(const h16x8*)(ur + c);
+    h16x8 xf[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) xf[t] = *(const bf16x8*)(xr + (int64_t)(t * 16 + fr) * L * D + c);
+    for (int t = 0; t < NT; ++t) xf[t] = *(const h16x8*)(xr + (int64_t)(t * 16 + fr) * L * D + c);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
       // MSA rows as MFMA-A, heads as MFMA-B: lane holds D[n = 16 t + 4 fq + r][h = fr]
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[t], uf, acc[t], 0, 0, 0);
+      acc[t] = rf_mfma16(xf[t], uf, acc[t], 0, 0, 0);
   }
   float mx = -INFINITY;
 #pragma unroll
@@ -707,7 +707,7 @@ extern "C" int rf_poswise_collapsed(const void* xn, const void* u, float* w, int
   hipStream_t s = (hipStream_t)stream;
 #define RF_PW(NT_)                                                                                                           \
   if (N == 16 * NT_) {                                                                                                       \
-    hipLaunchKernelGGL(poswise_mfma_kernel<NT_>, dim3(grid), dim3(256), 0, s, (const bf16_t*)xn, (const bf16_t*)u, w, B, N, \
+    hipLaunchKernelGGL(poswise_mfma_kernel<NT_>, dim3(grid), dim3(256), 0, s, (const h16_t*)xn, (const h16_t*)u, w, B, N, \
                        L, D, H, scale);                                                                                      \
     return rf_launch_status();                                                                                               \
   }

@@ -6,7 +6,8 @@ the dispatcher -- there is no CPU kernel), a device guard around the launch (the
 current stream), and a fake ("meta") implementation for shape inference, so the ops compose with FakeTensor tracing and
 `torch.library.opcheck`.
 
-The model's own forward calls the same C entry points through ops.py directly: one dispatcher hop costs ~15-20 us of
+"bf16" below = the 16-bit operand type of the active library (bfloat16, or float16 after
+set_compute_dtype(torch.float16)).  The model's own forward calls the same C entry points through ops.py directly: one dispatcher hop costs ~15-20 us of
 host time per op (tools/custom_op_overhead.py), the forward issues ~4,000 launches per step and some of them run for
 10-30 us, so routing the hot path through the dispatcher would make it host-bound.  Both routes end in the same kernels.
 
@@ -27,7 +28,7 @@ from torch import Tensor
 from . import _lib as L
 from . import ops
 
-BF16, F32 = torch.bfloat16, torch.float32
+F32 = torch.float32
 
 
 def _guard(t):
@@ -48,12 +49,12 @@ def _(x, w, bias, act, out_fp32):
 @torch.library.custom_op("rfmi::layernorm", mutates_args=(), device_types="cuda")
 def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_fp32: bool) -> Tensor:
     with _guard(x):
-        return ops.layernorm(x.contiguous(), gamma, beta, eps=eps, out_dtype=F32 if out_fp32 else BF16)
+        return ops.layernorm(x.contiguous(), gamma, beta, eps=eps, out_dtype=F32 if out_fp32 else ops.h16())
 
 
 @layernorm.register_fake
 def _(x, gamma, beta, eps, out_fp32):
-    return x.new_empty(x.shape, dtype=F32 if out_fp32 else BF16)
+    return x.new_empty(x.shape, dtype=F32 if out_fp32 else ops.h16())
 
 
 @torch.library.custom_op("rfmi::tied_row_attention", mutates_args=(), device_types="cuda")
@@ -77,7 +78,7 @@ def performer_attention(qkv: Tensor, proj: Tensor, heads: int, softmax_kernel: b
     S, n, W3 = qkv.shape
     inner = W3 // 3
     with _guard(qkv):
-        out = torch.empty(S, n, inner, device=qkv.device, dtype=BF16)
+        out = torch.empty(S, n, inner, device=qkv.device, dtype=qkv.dtype)
         ops.favor_attention(qkv.contiguous(), proj.contiguous(), out, (0, n * W3, W3, 64), (0, n * inner, inner), 0, inner,
                             2 * inner, 1, S, heads, n, 64, 266, softmax_kernel, 1e-4 if softmax_kernel else 1e-3)
     return out

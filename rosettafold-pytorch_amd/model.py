@@ -33,6 +33,10 @@ VT_ROWS = 80   # 64 value rows + the ones row (k' sums) padded to a multiple of 
 
 class _Runtime:
     dtype = torch.bfloat16
+    # structure-track node input (LayerNorm(msa) -> position-weighted sum, rf.py:789-798) in fp32 also in the 16-bit modes:
+    # the SE(3) stack is discontinuous (GNormBias, kNN, distance bins), so its inputs are not the place to round
+    # (tools/depth_parity.py --struct-lowp measures the difference)
+    struct_inputs_fp32 = True
     fused_favor = True  # use the fused FAVOR+ kernel when the shape allows (bf16, dim_head 64, seq 128/256)
     fused_outer_ln = not bool(int(__import__("os").environ.get("RF_NO_FUSED_OUTER_LN", "0")))  # LayerNorm(1024) in the outer-product GEMM epilogue
     fused_tied = not bool(int(__import__("os").environ.get("RF_NO_FUSED_TIED", "0")))  # tied-attention logits + softmax in one launch
@@ -63,10 +67,17 @@ RT = _Runtime()
 
 
 def set_compute_dtype(dtype):
-    """torch.bfloat16 (MFMA path, default) or torch.float32 (exact fp32 path used for parity)."""
-    if dtype not in (torch.bfloat16, torch.float32):
-        raise TypeError("compute dtype must be bfloat16 or float32")
+    """Operand type of the dense contractions (accumulation, residual streams, statistics and the structure track are
+    fp32 in every mode):
+      torch.bfloat16  v_mfma_f32_16x16x32_bf16, librfmi.so (default: the dtype BASELINE.json quotes the metric on);
+      torch.float16   v_mfma_f32_16x16x32_f16, librfmi_f16.so: same rate and bytes, 8x smaller operand rounding
+                      (11 significand bits), fp16 range -- the mode that carries the whole-model parity claim at speed;
+      torch.float32   exact fp32 tiles (v_mfma_f32_16x16x4_f32, 1/16 of the rate): the strict oracle-parity mode.
+    Kernel-ready weight copies are cached per dtype, so switching back and forth costs nothing after the first forward."""
+    if dtype not in (torch.bfloat16, torch.float16, torch.float32):
+        raise TypeError("compute dtype must be bfloat16, float16 or float32")
     RT.dtype = dtype
+    L.select_h16(L.RF_F16 if dtype == torch.float16 else L.RF_BF16)
 
 
 def T():
@@ -458,7 +469,7 @@ class SoftTiedAttentionOverResidues(RFModule):
         H, dh = self.n_heads, self.d_head
         dev = xn.device
         pw = self.poswise_weight
-        if (RT.fused_tied and RT.tied_v2 and T() == torch.bfloat16 and dh == 32 and Lr in (64, 128, 192, 256) and H <= 16
+        if (RT.fused_tied and RT.tied_v2 and ops.is_h16(T()) and dh == 32 and Lr in (64, 128, 192, 256) and H <= 16
                 and N % 16 == 0 and N // 16 in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16) and (B * N * Lr) % 256 == 0 and B * N * Lr >= 16384
                 and (6 if Lr >= 256 else 8) * (4096 + Lr * 64) + 1024 + N * 256 <= 160 * 1024):
             return self.attend_head_major(xn, x_res, want_att, next_ln)
@@ -477,7 +488,7 @@ class SoftTiedAttentionOverResidues(RFModule):
         W3 = 3 * D
         att = torch.empty(B, H, Lr, Lr, device=dev, dtype=T())
         att_sym = torch.empty(B, Lr, Lr, H, device=dev, dtype=F32) if want_att else None
-        if RT.fused_tied and T() == torch.bfloat16 and dh == 32 and Lr in (64, 128, 192, 256):
+        if RT.fused_tied and ops.is_h16(T()) and dh == 32 and Lr in (64, 128, 192, 256):
             # one launch: 6-8-stage DMA ring over the N steps, logits in registers, wave-local softmax (csrc/tied.hip)
             ops.tied_logits_softmax(qkp, qkp[..., D:], N * Lr * W3, Lr * W3, W3, att, att_sym, B, H, N, Lr, dh)
         else:
@@ -597,7 +608,7 @@ class PerformerSelfAttention(RFModule):
         m = self.fast_attention.projection_matrix.shape[0]
         pc = self.proj_scaled()
         gen = self.generalized
-        if RT.fused_favor and T() == torch.bfloat16 and dh == 64 and m == M_FEAT and (
+        if RT.fused_favor and ops.is_h16(T()) and dh == 64 and m == M_FEAT and (
                 Ls in (64, 128, 256) or (gen and Ls > 256 and Ls % 256 == 0)):
             # fused path: one projection GEMM (q|k|v) + one persistent kernel; q', k', ctx never leave the chip
             W3 = 3 * inner
@@ -772,7 +783,7 @@ class OuterProductMean(RFModule):
         self.to_out = nn.Sequential(LayerNorm(in_features ** 2), Linear(in_features ** 2, out_features))
 
     def fused_ok(self, P, N, Lr):
-        return (RT.fused_outer and T() == torch.bfloat16 and P == 32 and N in (64, 128) and Lr % 16 == 0
+        return (RT.fused_outer and ops.is_h16(T()) and P == 32 and N in (64, 128) and Lr % 16 == 0
                 and self.to_out[1].weight.shape[0] == 288)
 
     def run_into(self, x_t, y_t, ln2, feat, feat_ld):
@@ -797,7 +808,7 @@ class OuterProductMean(RFModule):
             out = torch.empty(B, Lr, Lr, lin.weight.shape[0], device=x_t.device, dtype=F32)
             return ops.outer_fused(x_t, y_t, wp, s_, c_, out, lnm.eps)
         co = torch.empty(B, Lr, Lr, PP, device=x_t.device, dtype=T())
-        if T() == torch.bfloat16 and P == 32 and (Lr * P) % 256 == 0 and N >= 64 and RT.fused_outer_ln:
+        if ops.is_h16(T()) and P == 32 and (Lr * P) % 256 == 0 and N >= 64 and RT.fused_outer_ln:
             # LayerNorm(1024) of every pair's outer-product block inside the GEMM epilogue (fp32 statistics on the
             # accumulators): the separate pass over the 0.5 GB feature tensor disappears
             ops.gemm(x_t, y_t, co, Lr * P, Lr * P, N, batch=(B, 1, 1), a_bs=(Lr * P * N, 0, 0), b_bs=(Lr * P * N, 0, 0),
@@ -1132,7 +1143,8 @@ class GraphTransformerBlock(RFModule):
 def _node_input(mod, msa, seq_onehot, out_dtype=None):
     """[sum_n w*LN(msa) | onehot] zero-padded to a multiple of 8 columns, T (rf.py:715-724, 789-798)."""
     B, N, Lr, D = msa.shape
-    m = ln(mod.ln_msa, msa)
+    # the fp32 (structure-track) form keeps LayerNorm(msa) in fp32 too: nothing upstream of the SE(3) stack is rounded
+    m = ln(mod.ln_msa, msa, out_dtype=F32 if (out_dtype == F32 and RT.struct_inputs_fp32) else None)
     w = mod.poswise_weight.weights_collapsed(msa, mod.ln_msa, m)
     Kp = pad8(D + 21)
     tmp = ops.zeros(B, Lr, Kp, device=msa.device, dtype=F32)

@@ -14,15 +14,31 @@ import torch
 from . import _lib as L
 from ._lib import lib, check, GemmDesc, I64x4, I64x3
 
-F32, BF16 = torch.float32, torch.bfloat16
+F32, BF16, F16 = torch.float32, torch.bfloat16, torch.float16
+_H16_CODE = {torch.bfloat16: L.RF_BF16, torch.float16: L.RF_F16}
+_H16_TORCH = {L.RF_BF16: torch.bfloat16, L.RF_F16: torch.float16}
+
+
+def is_h16(dtype):
+    """A 16-bit MFMA operand type (bfloat16: librfmi.so, float16: librfmi_f16.so)."""
+    return dtype in _H16_CODE
+
+
+def h16():
+    """torch dtype of the 16-bit operand type of the library that is active now (model.set_compute_dtype)."""
+    return _H16_TORCH[L.active_h16()]
 
 
 def dcode(dtype):
     if dtype == torch.float32:
         return L.RF_F32
-    if dtype == torch.bfloat16:
-        return L.RF_BF16
-    raise TypeError(f"unsupported dtype {dtype}")
+    code = _H16_CODE.get(dtype)
+    if code is None:
+        raise TypeError(f"unsupported dtype {dtype}")
+    if code != L.active_h16():  # (the library would reject the code too: this names the cause)
+        raise L.RfmiError(f"{dtype} tensor passed while the active library computes in {h16()} "
+                          "(set_compute_dtype selects the library)")
+    return code
 
 
 def stream():
@@ -32,6 +48,9 @@ def stream():
 def ptr(t, off_elems=0):
     if t is None:
         return None
+    if t.dtype in _H16_CODE and _H16_CODE[t.dtype] != L.active_h16():
+        # entry points without a dtype argument read 16-bit memory as the active library's type: never hand them the other one
+        raise L.RfmiError(f"{t.dtype} tensor passed while the active library computes in {h16()}")
     return C.c_void_p(t.data_ptr() + off_elems * t.element_size())
 
 
@@ -196,10 +215,10 @@ def tied_attention(q, k, v, out, att, w=None, qscale=1.0, att_sym=None, partial_
 
 
 def tied_row_attention(q, k, v):
-    """Functional form for the dispatcher op: q, k, v bf16 [B, N, L, H, 32] -> (out [B, N, L, H*32], att_sym [B, L, L, H])."""
+    """Functional form for the dispatcher op: q, k, v h16 [B, N, L, H, 32] -> (out [B, N, L, H*32], att_sym [B, L, L, H])."""
     B, N, L_, H, dh = q.shape
-    out = torch.empty(B, N, L_, H * dh, device=q.device, dtype=BF16)
-    att = torch.empty(B, H, L_, L_, device=q.device, dtype=BF16)
+    out = torch.empty(B, N, L_, H * dh, device=q.device, dtype=q.dtype)
+    att = torch.empty(B, H, L_, L_, device=q.device, dtype=q.dtype)
     sym = torch.empty(B, L_, L_, H, device=q.device, dtype=F32)
     hm = lambda t: t.permute(0, 1, 3, 2, 4)  # noqa: E731  [B, N, H, L, 32] view
     tied_attention(hm(q.contiguous()), hm(k.contiguous()), hm(v.contiguous()), hm(out.view(B, N, L_, H, dh)), att, att_sym=sym)
@@ -222,20 +241,20 @@ def outer_fused(xt, yt, wprime, s, c, out, eps, ln2=None):
     return y if ln2 is not None else out
 
 
-def outer_fold(w, gamma, beta, bias):
-    """(W * gamma in bf16, its fp32 row sums, W beta + bias): the LayerNorm(1024) affine folded into Linear(1024 -> Dout)."""
-    wp = (w.float() * gamma.float()[None, :]).to(BF16).contiguous()
+def outer_fold(w, gamma, beta, bias, dtype=None):
+    """(W * gamma in the 16-bit type, its fp32 row sums, W beta + bias): the LayerNorm(1024) affine folded into Linear(1024 -> Dout)."""
+    wp = (w.float() * gamma.float()[None, :]).to(dtype or h16()).contiguous()
     return wp, wp.float().sum(1).contiguous(), (w.float() @ beta.float() + bias.float()).contiguous()
 
 
 def outer_product_ln_linear(x, y, gamma, beta, w, b, eps):
     """Functional form (dispatcher op): x, y bf16 [B, N, L, 32] -> fp32 [B, L, L, Dout]."""
     B, N, L_, P = x.shape
-    xt = torch.empty(B, L_, P, N, device=x.device, dtype=BF16)
-    yt = torch.empty(B, L_, P, N, device=x.device, dtype=BF16)
+    xt = torch.empty(B, L_, P, N, device=x.device, dtype=x.dtype)
+    yt = torch.empty(B, L_, P, N, device=x.device, dtype=x.dtype)
     for src, dst in ((x, xt), (y, yt)):
         copy4d(src.contiguous(), (N * L_ * P, P, 1, L_ * P), dst, (L_ * P * N, P * N, N, 1), (B, L_, P, N))
-    wp, s, c = outer_fold(w, gamma, beta, b)
+    wp, s, c = outer_fold(w, gamma, beta, b, x.dtype)
     out = torch.empty(B, L_, L_, w.shape[0], device=x.device, dtype=F32)
     return outer_fused(xt, yt, wp, s, c, out, eps)
 
@@ -526,8 +545,8 @@ def add_pos_enc(x, aa_idx, pe, two_d):
 def favor_attention(qkv, pc, out, x_strides, o_strides, q_off, k_off, v_off, n_b, n_o, n_h, seq_len, dim_head,
                     n_features, softmax_kernel, eps):
     _need_cuda(qkv, pc, out)
-    if qkv.dtype != BF16 or pc.dtype != BF16 or out.dtype != BF16:
-        raise TypeError("favor_attention is the bf16 MFMA path")
+    if not (is_h16(qkv.dtype) and pc.dtype == qkv.dtype and out.dtype == qkv.dtype):
+        raise TypeError("favor_attention is the 16-bit MFMA path (q|k|v, projection and output in the library's 16-bit type)")
     xs = L.I64x4(*[int(v) for v in x_strides])
     os_ = L.I64x3(*[int(v) for v in o_strides])
     check(lib.rf_favor_attention(ptr(qkv), ptr(pc), ptr(out), C.byref(xs), C.byref(os_), q_off, k_off, v_off, n_b, n_o,
@@ -551,8 +570,8 @@ def linear_residual_ln(x, w, bias, x_res, next_ln):
     N = w.shape[0]
     # N == 288 with whole 256-row panels: the persistent GEMM normalises the rows in its epilogue (csrc/gemm_fast.hip)
     fused = FUSE_LN or (FUSE_LN_288 and N == 288 and (x_res.numel() // N) % 256 == 0 and (x_res.numel() // N) >= 16384)
-    if fused and next_ln is not None and x.dtype == BF16 and N <= 384 and N % 4 == 0 and x_res.is_contiguous():
-        xn = torch.empty(x_res.shape, device=x_res.device, dtype=BF16)
+    if fused and next_ln is not None and is_h16(x.dtype) and N <= 384 and N % 4 == 0 and x_res.is_contiguous():
+        xn = torch.empty(x_res.shape, device=x_res.device, dtype=x.dtype)
         linear(x, w, bias, out=x_res, residual=x_res,
                ln=(xn, next_ln.weight.detach(), next_ln.bias.detach(), next_ln.eps))
         return xn

@@ -9,7 +9,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, "include", "rfmi.h")
-LIB = os.path.join(ROOT, "rosettafold-pytorch_amd", "librfmi.so")
+LIBS = [os.path.join(ROOT, "rosettafold-pytorch_amd", n) for n in ("librfmi.so", "librfmi_f16.so")]
 
 
 def declared():
@@ -18,11 +18,12 @@ def declared():
     return sorted(set(re.findall(r"\b(rf_[a-z0-9_]+)\s*\(", src)))
 
 
-@pytest.fixture(scope="module")
-def lib():
-    if not os.path.exists(LIB):
+@pytest.fixture(scope="module", params=LIBS, ids=["bf16-build", "f16-build"])
+def lib(request):
+    """both builds of the kernel sources (16-bit operand type bfloat16 / IEEE fp16) export the whole header"""
+    if not os.path.exists(request.param):
         subprocess.run(["make", "-C", os.path.join(ROOT, "rosettafold-pytorch_amd", "csrc"), "-j8"], check=True)
-    return ctypes.CDLL(LIB)
+    return ctypes.CDLL(request.param)
 
 
 def test_every_declared_symbol_is_exported(lib):
@@ -36,6 +37,18 @@ def test_ctypes_table_matches_header():
     from rosettafold_pytorch_amd import _lib
     assert sorted(set(_lib.PROTOTYPES) | {"rf_build_info"}) == declared()
     assert _lib.lib.rf_version() >= 1
+    # the two builds say which 16-bit dtype code they take, and the selector routes to the matching one
+    assert _lib.LIBS[_lib.RF_BF16].rf_h16_dtype() == _lib.RF_BF16 and _lib.LIBS[_lib.RF_F16].rf_h16_dtype() == _lib.RF_F16
+    import torch
+    import rosettafold_pytorch_amd as R
+    try:
+        R.set_compute_dtype(torch.float16)
+        assert _lib.lib.rf_h16_dtype() == _lib.RF_F16 and b"fp16" in _lib.lib.rf_build_info()
+        with pytest.raises(_lib.RfmiError):  # a bfloat16 tensor is never handed to the fp16 build
+            R.ops.dcode(torch.bfloat16)
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    assert _lib.lib.rf_h16_dtype() == _lib.RF_BF16
 
 
 def test_gemm_desc_layout_matches_c():

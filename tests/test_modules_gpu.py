@@ -14,7 +14,7 @@ import rosettafold_pytorch_amd as R  # noqa: E402
 from oracle import rf_oracle as O  # noqa: E402
 
 DEV = "cuda"
-MODES = [(torch.float32, 2e-4), (torch.bfloat16, 4e-2)]
+MODES = [(torch.float32, 2e-4), (torch.bfloat16, 4e-2), (torch.float16, 6e-3)]  # (compute dtype, max-norm tolerance)
 B, N, Lr, DM, DP, DN, DE, DS = 2, 8, 16, 96, 72, 8, 8, 8
 
 
@@ -44,7 +44,7 @@ def build(ctor, seed=11):
     return ctor().to(DEV)
 
 
-@pytest.fixture(params=MODES, ids=["fp32", "bf16"])
+@pytest.fixture(params=MODES, ids=["fp32", "bf16", "fp16"])
 def mode(request):
     R.set_compute_dtype(request.param[0])
     yield request.param
@@ -113,9 +113,10 @@ def test_performer_self_attention(mode, generalized):
 
 @pytest.mark.parametrize("generalized,n", [(False, 64), (True, 64), (False, 128), (True, 128), (False, 256), (True, 256),
                                            (True, 512), (True, 1024)])
-def test_fused_favor_attention(generalized, n):
-    """fused FAVOR+ kernel (seq 128/256, bf16) vs the CPU oracle and vs the unfused kernel chain."""
-    R.set_compute_dtype(torch.bfloat16)
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_fused_favor_attention(generalized, n, dt):
+    """fused FAVOR+ kernel (seq 64..1024, both 16-bit builds) vs the CPU oracle and vs the unfused kernel chain."""
+    R.set_compute_dtype(dt)
     m = build(lambda: R.PerformerSelfAttention(dim=DP, heads=3, generalized_attention=generalized))
     x = rn(5, n, DP)
     ref = O.performer_self_attention(state(m), "m", x, 3, generalized)
@@ -128,9 +129,15 @@ def test_fused_favor_attention(generalized, n):
     # sit at the edge of it (4.02e-2 at n=128 on this seed), so their max-norm bound is 4.5e-2.  The relative-L2 bound,
     # 2e-2, is the same for both and is the one DESIGN.md states.
     tol = 4e-2 if generalized else 4.5e-2
-    assert rel(y_u, ref) < tol
-    assert rel(y_f, ref) < tol, (rel(y_f, ref), rel(y_f, y_u))
-    assert rel2(y_f, ref) < 2e-2
+    l2 = 2e-2
+    if dt == torch.float16:  # fp16 operands: 8x less rounding (and the sequence-scaled context of the f16 build, favor.hip FV_CS)
+        tol, l2 = 6e-3, 3e-3
+    try:
+        assert rel(y_u, ref) < tol
+        assert rel(y_f, ref) < tol, (rel(y_f, ref), rel(y_f, y_u))
+        assert rel2(y_f, ref) < l2
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
 
 
 def test_fused_favor_axis1_strides():
