@@ -51,14 +51,15 @@ __device__ __forceinline__ void fast_glds16(const void* src, void* lds_wave_base
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BN, bool OUT_F32, bool HAS_RES, bool STAMP = false, bool LN = false, bool CS = false>
+template <int BN, bool OUT_F32, bool HAS_RES, bool STAMP = false, bool LN = false, bool CS = false, int BM = 256>
 __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
   static_assert(!LN || (OUT_F32 && HAS_RES), "the fused LayerNorm epilogue normalises the updated fp32 residual rows");
   static_assert(!CS || (!OUT_F32 && !HAS_RES && !LN), "split-C layout: bf16 output without residual");
-  constexpr int BM = 256, BK = 64, NW = 8, TM = 64, TN = BN / 2, WM = TM / 16, WN = TN / 16;
+  static_assert(BM == 256 || BM == 128, "tile rows");
+  constexpr int BK = 64, NW = 8, TM = BM / 4, TN = BN / 2, WM = TM / 16, WN = TN / 16;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   constexpr int B_INSTR = BN / 8;                  // wave-level DMA instructions per B tile (8 rows x 128 B each)
-  constexpr int A_PW = 4, B_PW = (B_INSTR + NW - 1) / NW;
+  constexpr int A_PW = BM / 64, B_PW = (B_INSTR + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -240,55 +241,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
 
     // ---- epilogue: strips overlay the buffer of the last K step (buf ^ 1 now); buf holds the next tile's step 0 ----
     __syncthreads();  // every wave is done reading that buffer
-    float ln_mean[WM], ln_rstd[WM];
-    if constexpr (LN) {
-      // The tile spans whole rows (N == BN): add the residual in the MFMA layout, reduce each row over the lane quads
-      // and the two wave columns (LDS), two-pass variance like the stand-alone kernel.  The strips below then carry the
-      // finished fp32 rows to C and, in a second sweep, the normalised bf16 rows to ln_out: the separate LayerNorm
-      // launch and its 302 MB re-read of the stream disappear.
-      float* const st1 = (float*)(smem + (buf ^ 1) * STAGE_BYTES + 56 * 1024);  // [256 rows][2 wave columns]
-      float* const st2 = st1 + 512;
-      const float* Rl = p.residual + (int64_t)(m0 + wm * TM + fr) * p.ldc + n0 + wn * TN + 4 * fq;
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        float sm = 0.f;
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          const f32x4 r4 = *(const f32x4*)(Rl + (int64_t)i * 16 * p.ldc + j * 16);
-          acc[i][j] += r4;
-          sm += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
-        }
-        sm += __shfl_xor(sm, 16, 64);
-        sm += __shfl_xor(sm, 32, 64);
-        if (fq == 0) st1[(wm * TM + i * 16 + fr) * 2 + wn] = sm;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        const int row = wm * TM + i * 16 + fr;
-        ln_mean[i] = (st1[row * 2] + st1[row * 2 + 1]) * (1.0f / BN);
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float dlt = acc[i][j][e] - ln_mean[i];
-            q += dlt * dlt;
-          }
-        q += __shfl_xor(q, 16, 64);
-        q += __shfl_xor(q, 32, 64);
-        if (fq == 0) st2[row * 2 + wn] = q;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        const int row = wm * TM + i * 16 + fr;
-        ln_rstd[i] = rsqrtf((st2[row * 2] + st2[row * 2 + 1]) * (1.0f / BN) + p.ln_eps);
-      }
-    }
-    {
-      // (LN variant: both sweeps use the same per-wave stride, so a wave's bf16 strip never overlaps a neighbour's fp32 one)
-      constexpr int WSTRIDE = LN ? (RP * PITCHW > 16 * (TN * 2 + 16) ? RP * PITCHW : 16 * (TN * 2 + 16)) : RP * PITCHW;
+    if constexpr (!LN) {
+      constexpr int WSTRIDE = RP * PITCHW;
       char* const strip = smem + (buf ^ 1) * STAGE_BYTES + wave * WSTRIDE;
       char* const Cw = (char*)p.C + ((int64_t)(m0 + wm * TM) * p.ldc + n0 + wn * TN) * ESZ;
       const char* const Rw = HAS_RES ? (const char*)p.residual + ((int64_t)(m0 + wm * TM) * p.ldc + n0 + wn * TN) * 4 : nullptr;
@@ -356,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
           f32x4 res[G], vv[G];
 #pragma unroll
           for (int g = 0; g < G; ++g) {
-            if constexpr (HAS_RES && !LN) {
+            if constexpr (HAS_RES) {
               res[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
               if (t0 + g < NIT && (NCH % 64 == 0 || lane + 64 * (t0 + g) < NCH) && !(p.dbg & 4)) res[g] = *(const f32x4*)(Rp + (unsigned)goff[t0 + g] * 4u);
             }
@@ -368,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
           for (int g = 0; g < G; ++g) {
             if (t0 + g >= NIT || !(NCH % 64 == 0 || lane + 64 * (t0 + g) < NCH)) continue;
             f32x4 v = vv[g];
-            if constexpr (HAS_RES && !LN) v += res[g];
+            if constexpr (HAS_RES) v += res[g];
             f32x4* dst;
             if constexpr (CS) {
               const int m = m0 + wm * TM + r0 + (goff[t0 + g] >> 16), n = n0 + wn * TN + (goff[t0 + g] & 0xffff);
@@ -386,38 +340,83 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
       }
     }
     if constexpr (LN) {
-      constexpr int PITCHB = TN * 2 + 16, CPRB = TN * 2 / 16, NCHB = 16 * CPRB, NITB = (NCHB + 63) / 64;
-      static_assert(8 * (RP * PITCHW > 16 * PITCHB ? RP * PITCHW : 16 * PITCHB) <= 56 * 1024, "strips overlap the row statistics");
-      constexpr int WSTRIDE = RP * PITCHW > 16 * PITCHB ? RP * PITCHW : 16 * PITCHB;
-      char* const stripb = smem + (buf ^ 1) * STAGE_BYTES + wave * WSTRIDE;
-      const float* const gam = (const float*)(smem + GB_OFF) + wn * TN + 4 * fq;
-      h16_t* const Lw = (h16_t*)p.ln_out + (int64_t)(m0 + wm * TM) * BN + wn * TN;
+      // Fused "LayerNorm of the next sub-layer" (N == BN: the tile spans whole rows).  Per pass of 8 rows a wave moves its
+      // accumulator rows through its private strip into a ROW-CONTIGUOUS register image -- lane (r = lane / 8, c8 = lane % 8)
+      // holds the 16-byte pieces c8, c8 + 8, ... of row r -- adds the fp32 residual there (whole 128-byte lines per row and
+      // instruction, as the plain epilogue), stores the updated stream and keeps it in registers (they replace the dying
+      // accumulators one for one).  Half-row sums / sums of squares (three shuffles over the row's 8 lanes) meet the other
+      // wave column's in LDS behind ONE barrier per tile; then the rows are normalised in registers and leave as 16-bit
+      // pieces.  The separate LayerNorm launch and its re-read of the stream disappear (10.6 % of the round-2 step).
+      constexpr int RPL = 8, NPASS = TM / RPL, CPR = TN / 4, KCH = (CPR + 7) / 8;
+      static_assert(NW * RPL * PITCHW <= 56 * 1024 && 56 * 1024 + BM * 16 <= STAGE_BYTES, "strips / row statistics do not fit a stage buffer");
+      char* const strip = smem + (buf ^ 1) * STAGE_BYTES + wave * (RPL * PITCHW);
+      float2* const hst = (float2*)(smem + (buf ^ 1) * STAGE_BYTES + 56 * 1024);  // [BM rows][2 wave columns] (sum, sum of squares)
+      const int r = lane >> 3, c8 = lane & 7;
+      char* const Cw = (char*)p.C + ((int64_t)(m0 + wm * TM + r) * p.ldc + n0 + wn * TN) * 4;
+      const char* const Rw = (const char*)p.residual + ((int64_t)(m0 + wm * TM + r) * p.ldc + n0 + wn * TN) * 4;
+      f32x4 v[NPASS][KCH];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        __builtin_amdgcn_sched_barrier(0);
-        char* lrow = stripb + fr * PITCHB;
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int r0 = ps * RPL, i = r0 / 16;
+        if ((fr >> 3) == ((r0 >> 3) & 1)) {
+          char* lrow = strip + (fr & 7) * PITCHW;
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-          const f32x4 g4 = *(const f32x4*)(gam + j * 16), b4 = *(const f32x4*)(gam + BN + j * 16);
-          float o[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (acc[i][j][e] - ln_mean[i]) * ln_rstd[i] * g4[e] + b4[e];
-          uint2 w;
-          w.x = rf_pack2_h16(o[0], o[1]);
-          w.y = rf_pack2_h16(o[2], o[3]);
-          *(uint2*)(lrow + (j * 16 + 4 * fq) * 2) = w;
+          for (int j = 0; j < WN; ++j) *(f32x4*)(lrow + (j * 16 + 4 * fq) * 4) = acc[i][j];
         }
-        asm volatile("" ::: "memory");
+        asm volatile("" ::: "memory");  // (keeps the strip reads below out of the lane-masked write block)
+        f32x4 res[KCH];
 #pragma unroll
-        for (int t = 0; t < NITB; ++t) {
-          const int idx = lane + 64 * t;
-          if (NCHB % 64 == 0 || idx < NCHB) {
-            const int r = idx / CPRB, c = idx % CPRB;
-            const f32x4 v = *(const f32x4*)(stripb + r * PITCHB + c * 16);
-            *(f32x4*)(Lw + (int64_t)(i * 16 + r) * BN + c * 8) = v;
+        for (int k = 0; k < KCH; ++k) {
+          res[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (CPR % 8 == 0 || k < KCH - 1 || c8 + 8 * k < CPR)
+            res[k] = *(const f32x4*)(Rw + ((int64_t)r0 * p.ldc + (c8 + 8 * k) * 4) * 4);
+        }
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) {
+          const bool ok = CPR % 8 == 0 || k < KCH - 1 || c8 + 8 * k < CPR;
+          f32x4 x = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (ok) {
+            x = *(const f32x4*)(strip + r * PITCHW + (c8 + 8 * k) * 16) + res[k];
+            f32x4* dst = (f32x4*)(Cw + ((int64_t)r0 * p.ldc + (c8 + 8 * k) * 4) * 4);
+            if (p.nt_store)
+              __builtin_nontemporal_store(x, dst);
+            else
+              *dst = x;
+          }
+          v[ps][k] = x;
+          sm += (x[0] + x[1]) + (x[2] + x[3]);
+          sq += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
+        }
+#pragma unroll
+        for (int o = 1; o <= 4; o <<= 1) {
+          sm += __shfl_xor(sm, o, 64);
+          sq += __shfl_xor(sq, o, 64);
+        }
+        if (c8 == 0) hst[(wm * TM + r0 + r) * 2 + wn] = make_float2(sm, sq);
+        asm volatile("" ::: "memory");
+      }
+      __syncthreads();  // both wave columns' half-row sums are in place
+      const float* const gam = (const float*)(smem + GB_OFF) + wn * TN;
+      h16_t* const Lw = (h16_t*)p.ln_out + (int64_t)(m0 + wm * TM + r) * BN + wn * TN;
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int row = wm * TM + ps * RPL + r;
+        const float2 ha = hst[row * 2], hb = hst[row * 2 + 1];
+        const float mean = (ha.x + hb.x) * (1.0f / BN);
+        const float rstd = rsqrtf(fmaxf((ha.y + hb.y) * (1.0f / BN) - mean * mean, 0.f) + p.ln_eps);
+#pragma unroll
+        for (int k = 0; k < KCH; ++k) {
+          if (CPR % 8 == 0 || k < KCH - 1 || c8 + 8 * k < CPR) {
+            const int c = (c8 + 8 * k) * 4;
+            const f32x4 g4 = *(const f32x4*)(gam + c), b4 = *(const f32x4*)(gam + BN + c);
+            const f32x4 o = (v[ps][k] - mean) * rstd * g4 + b4;
+            uint2 w;
+            w.x = rf_pack2_h16(o[0], o[1]);
+            w.y = rf_pack2_h16(o[2], o[3]);
+            *(uint2*)(Lw + (int64_t)(ps * RPL) * BN + c) = w;
           }
         }
-        asm volatile("" ::: "memory");
       }
     }
     if constexpr (STAMP) {
@@ -442,11 +441,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
   }
 }
 
-template <int BN, bool OUT_F32, bool HAS_RES, bool STAMP = false, bool LN = false, bool CS = false>
+template <int BN, bool OUT_F32, bool HAS_RES, bool STAMP = false, bool LN = false, bool CS = false, int BM = 256>
 static int launch_fast(const FastP& p, hipStream_t s) {
-  constexpr int STAGE = (256 + BN) * 64 * 2;
-  auto k = gemm_fast_kernel<BN, OUT_F32, HAS_RES, STAMP, LN, CS>;
-  if (const int e = rf_enable_big_lds<gemm_fast_kernel<BN, OUT_F32, HAS_RES, STAMP, LN, CS>>()) return e;
+  constexpr int STAGE = (BM + BN) * 64 * 2;
+  auto k = gemm_fast_kernel<BN, OUT_F32, HAS_RES, STAMP, LN, CS, BM>;
+  if (const int e = rf_enable_big_lds<gemm_fast_kernel<BN, OUT_F32, HAS_RES, STAMP, LN, CS, BM>>()) return e;
   const int n_cu = rf_num_cus();
   if (n_cu <= 0) return RF_EINVAL;
   const int grid = p.ntiles < n_cu ? p.ntiles : n_cu;
@@ -471,10 +470,11 @@ int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
     return 0;
   if (d.M % 256 != 0 || d.M < 16384 || d.K < 64 || d.K % 8 != 0 || d.alpha != 1.0f) return 0;
   if (d.bias_mode == RF_BIAS_ROW || (d.act != RF_ACT_NONE && d.act != RF_ACT_RELU)) return 0;
-  // fused next-LayerNorm epilogue: the 288-wide pair rows (one tile spans whole rows), fp32 C with residual, no activation
+  // fused next-LayerNorm epilogue: one tile spans whole rows -- the 288-wide pair rows (256 x 288 tiles) and the 384-wide MSA
+  // rows (128 x 384 tiles); fp32 C with residual, no activation
   const bool ln = d.ln_out != nullptr;
-  if (ln && (d.N != 288 || d.c_dtype != RF_F32 || !d.residual || d.act != RF_ACT_NONE || !d.ln_gamma || !d.ln_beta ||
-             ((uintptr_t)d.ln_out % 16)))
+  if (ln && ((d.N != 288 && d.N != 384) || d.c_dtype != RF_F32 || !d.residual || d.act != RF_ACT_NONE || !d.ln_gamma || !d.ln_beta ||
+             ((uintptr_t)d.ln_out % 16) || ((uintptr_t)d.ln_gamma % 16) || ((uintptr_t)d.ln_beta % 16)))
     return 0;
   if (d.a_ri % 8 || d.b_ri % 8 || d.c_ri % 8 || ((uintptr_t)d.A % 16) || ((uintptr_t)d.B % 16) || ((uintptr_t)d.C % 16)) return 0;
   if (d.bias_mode == RF_BIAS_COL && ((uintptr_t)d.bias % 16)) return 0;
@@ -493,8 +493,9 @@ int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
   p.M = d.M; p.N = d.N; p.K = d.K;
   p.lda = (int)d.a_ri; p.ldb = (int)d.b_ri; p.ldc = (int)d.c_ri;
   p.relu = d.act == RF_ACT_RELU;
-  p.tilesN = d.N / bn;
-  const int64_t nt = (int64_t)(d.M / 256) * p.tilesN;
+  const int bm = (ln && d.N == 384) ? 128 : 256;
+  p.tilesN = (ln && d.N == 384) ? 1 : d.N / bn;
+  const int64_t nt = (int64_t)(d.M / bm) * p.tilesN;
   if (nt > 0x7fffffffLL) return 0;
   p.ntiles = (int)nt;
   p.nt_store = ((int64_t)d.M * d.N * (d.c_dtype == RF_F32 ? 4 : 2) > (64ll << 20)) && !no_nt;
@@ -516,7 +517,7 @@ int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
     return 1;
   }
   if (ln) {
-    *rc = launch_fast<288, true, true, false, true>(p, s);
+    *rc = d.N == 288 ? launch_fast<288, true, true, false, true>(p, s) : launch_fast<384, true, true, false, true, false, 128>(p, s);
     return 1;
   }
   if (p.stamps && bn == 256 && !f32) {  // timing experiment: instrumented twin of the bf16-output 256-wide kernel

@@ -6,10 +6,13 @@ the same seeded weights and inputs (one oracle forward, ~60-90 s of CPU, shared 
 Asserted (relative L2 over a whole tensor; distogram argmax agreement over all L x L pairs and over the pairs whose top-2
 oracle logits differ by more than 2 % of the map's range, "clear margin"):
 
-  mode   logits rel-L2   xyz rel-L2   argmax all pairs   argmax clear margin
-  fp32   < 5e-4          < 5e-4       == 1.0             == 1.0     exact fp32 tiles: the strict claim
-  fp16   < 2e-2          < 0.15       >= 0.95            >= 0.999   16-bit MFMA at full rate: the parity mode at speed
-  bf16   < 0.12          < 0.5        >= 0.80            >= 0.97    the dtype BASELINE.json quotes the metric on
+  mode   logits rel-L2   xyz rel-L2   argmax all pairs   argmax clear margin    observed (round 3, profiles/r03_depth_parity_oracle.json)
+  fp32   < 5e-4          < 5e-4       == 1.0 (distogram) == 1.0                 5.8e-6 / 9.3e-6 / 1.0 / 1.0
+  fp16   < 1e-2          < 0.15       >= 0.99            >= 0.999               3.4e-3 / 0.051  / 0.9958 / 1.0
+  bf16   < 6e-2          < 0.3        >= 0.93            >= 0.99                3.0e-2 / 0.114  / 0.9645 / 1.0
+(fp32: exact fp32 tiles, the strict claim; fp16: 16-bit MFMA at the full rate, the parity mode at speed; bf16: the dtype
+BASELINE.json quotes the metric on.  The other three maps (theta / phi / omega) must agree on >= 0.9999 of the pairs in
+fp32 mode: at random init single pairs are exact ties to the last bit.)
 
 tools/depth_parity.py prints the block-by-block error curves behind these numbers (profiles/r03_depth_parity*.json).
 """
@@ -41,16 +44,17 @@ def test_fp32_mode_matches_the_oracle_at_depth(result):
     r = result["fp32"]
     print("\n[depth fp32]", r["rel_l2"], r["dist_argmax_agreement"])
     assert all(v < 5e-4 for v in r["rel_l2"].values()), r["rel_l2"]
-    assert r["dist_argmax_agreement"] == 1.0 and all(v == 1.0 for v in r["argmax_agreement"].values())
+    assert r["dist_argmax_agreement"] == 1.0 and r["dist_argmax_agreement_clear_margin"] == 1.0
+    assert all(v >= 0.9999 for v in r["argmax_agreement"].values()), r["argmax_agreement"]
 
 
 def test_fp16_mode_meets_the_parity_bar_at_depth(result):
     r = result["fp16"]
     print("\n[depth fp16]", r["rel_l2"], r["dist_argmax_agreement"], r["dist_argmax_agreement_clear_margin"])
     for k in ("theta", "phi", "dist", "omega"):
-        assert r["rel_l2"][k] < 2e-2, (k, r["rel_l2"])
+        assert r["rel_l2"][k] < 1e-2, (k, r["rel_l2"])
     assert r["rel_l2"]["xyz"] < 0.15
-    assert r["dist_argmax_agreement"] >= 0.95
+    assert r["dist_argmax_agreement"] >= 0.99
     assert r["dist_argmax_agreement_clear_margin"] >= 0.999
 
 
@@ -58,10 +62,10 @@ def test_bf16_mode_bound_at_depth(result):
     r = result["bf16"]
     print("\n[depth bf16]", r["rel_l2"], r["dist_argmax_agreement"], r["dist_argmax_agreement_clear_margin"])
     for k in ("theta", "phi", "dist", "omega"):
-        assert r["rel_l2"][k] < 0.12, (k, r["rel_l2"])
-    assert r["rel_l2"]["xyz"] < 0.5
-    assert r["dist_argmax_agreement"] >= 0.80
-    assert r["dist_argmax_agreement_clear_margin"] >= 0.97
+        assert r["rel_l2"][k] < 6e-2, (k, r["rel_l2"])
+    assert r["rel_l2"]["xyz"] < 0.3
+    assert r["dist_argmax_agreement"] >= 0.93
+    assert r["dist_argmax_agreement_clear_margin"] >= 0.99
 
 
 def test_error_grows_monotonically_enough(result):
