@@ -95,6 +95,16 @@ typedef struct rf_gemm_desc {
   const float* ln_beta;
   float ln_eps;
   int32_t reserved_;
+  /* optional row-group scale of the leading output columns, applied to the fp32 accumulators (bias included) before the
+   * result is rounded:   C[m][n] *= rs_alpha * rs[(m / rs_rpb) * rs_bstride + (n / rs_cg) * rs_rpb + m % rs_rpb]   for n < rs_ncols.
+   * The q | k | v projection of the tied MSA-row attention folds the position weights into q this way (rf.py:252:
+   * q * w * d_head^-0.5 with w [B, H, N, L]: rs_rpb = N L, rs_bstride = H N L, rs_cg = d_head, rs_ncols = d_msa), so q is
+   * rounded once, after the scaling, and the attention kernels take it as it is.  16-bit path, register-resident-weights
+   * kernel only (K = 288 / 384, long M; rs_cg % 16 == 0): RF_EINVAL when rs != NULL and that kernel does not apply. */
+  const float* rs;
+  int64_t rs_bstride;
+  int32_t rs_rpb, rs_cg, rs_ncols;
+  float rs_alpha;
 } rf_gemm_desc;
 
 int rf_gemm(const rf_gemm_desc* d, void* stream);
@@ -166,7 +176,9 @@ int rf_poswise_collapsed(const void* xn, const void* u, float* w, int B, int N, 
 
 /* Fused OuterProductMean (rf.py:412-427): out[b,i,j,:] = Linear(LayerNorm_1024(sum_n x[b,n,i,:] (x) y[b,n,j,:])) in one
  * kernel; the 1024-wide feature tensor never exists in HBM.  xt / yt: bf16 [B, L, 32, N] (MSA depth contiguous);
- * wprime: bf16 [Dout, 1024] = W * gamma (LayerNorm affine folded in); s[o] = sum_k wprime[o,k] (fp32, of the bf16 values);
+ * wprime: 16-bit [16, Dout, 64] = W * gamma (LayerNorm affine folded in) stored CHUNK-MAJOR: wprime[c][o][8 uu + vv] =
+ * (W gamma)[o][k], k = (8 (c / 4) + uu) * 32 + 8 (c % 4) + vv -- the 64 features one chunk of the kernel contracts over are one
+ * 128-byte line per output column; s[o] = sum_k wprime[o,k] (fp32, of the 16-bit values);
  * c[o] = sum_k W[o,k] beta[k] + bias[o]; out: fp32 [B, L, L, Dout]:
  *     out = rstd * (sum_k co_k wprime[o,k] - mean * s[o]) + c[o],   mean / rstd over the 1024 features in fp32.
  * Supported: P == 32, Dout == 288, N in {64, 128}, L % 16 == 0 (RF_EINVAL otherwise: rf_gemm with RF_ACT_BLOCK_LN32 + rf_gemm). */
@@ -174,8 +186,9 @@ int rf_outer_product_ln_linear(const void* xt, const void* yt, const void* wprim
                                int B, int L, int N, int P, int Dout, float eps, const float* ln2_gamma, const float* ln2_beta,
                                float ln2_eps, void* y, int64_t y_ld, void* stream);
 /* Optional tail (PairUpdateWithMsa.ln_coevol_feat, rf.py:443,486): with y != NULL the kernel applies a second LayerNorm
- * (ln2_gamma / ln2_beta [Dout], ln2_eps) over the Dout outputs of every pair and writes bf16 y[(b,i,j) * y_ld + o] INSTEAD of
- * `out` (which may then be NULL): the fp32 result and the separate LayerNorm pass over it disappear as well. */
+ * (ln2_gamma / ln2_beta [Dout], ln2_eps) over the Dout outputs of every pair and writes 16-bit y[(b,i,j) * y_ld + o] INSTEAD of
+ * `out` (which may then be NULL): the fp32 result and the separate LayerNorm pass over it disappear as well.  y: 16-byte
+ * aligned, y_ld % 8 == 0 (rows leave as 16-byte pieces). */
 
 /* PositionWiseWeightFactor core (rf.py:205-217): w[b,n,h,l] = softmax_n( scale * sum_{c<dlen} q0[b,l,h,c]*k[b,n,l,h,c] ).
  * q0: [B,L,H*dlen] (dtype q0_dtype, ld q0_ld); k: T rows [B,N,L,*] of ld k_ld, head h at column k_col0 + h*k_hstride.

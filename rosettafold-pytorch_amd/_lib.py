@@ -31,6 +31,7 @@ class GemmDesc(C.Structure):
         ("act_eps", f32), ("alpha", f32), ("tile_cfg", i32),
         ("A", vp), ("B", vp), ("C", vp), ("bias", vp), ("residual", vp),
         ("ln_out", vp), ("ln_gamma", vp), ("ln_beta", vp), ("ln_eps", f32), ("reserved_", i32),
+        ("rs", vp), ("rs_bstride", i64), ("rs_rpb", i32), ("rs_cg", i32), ("rs_ncols", i32), ("rs_alpha", f32),
     ]
 
 

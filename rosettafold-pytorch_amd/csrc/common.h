@@ -126,6 +126,27 @@ static inline int rf_num_cus() {
   return prop.multiProcessorCount;
 }
 
+// Ablation / phase-timing switches (RF_GEMM_DBG, RF_TIED_DBG, RF_FAVOR_DBG: results are WRONG when set) exist only in a tuning
+// build (make ABLATION=1 -> -DRF_ABLATION).  In the production libraries RF_DBG() folds to 0 at compile time -- the kernels
+// carry neither the branches nor the registers of the instrumentation -- and an entry point that finds its switch set in the
+// environment refuses to launch (RF_EINVAL) instead of silently ignoring it.
+#ifdef RF_ABLATION
+#define RF_DBG(x) (x)
+static inline int rf_dbg_env(const char* name, int* out) {
+  static thread_local int dummy;
+  (void)dummy;
+  const char* v = getenv(name);
+  *out = v ? atoi(v) : 0;
+  return 0;
+}
+#else
+#define RF_DBG(x) 0
+static inline int rf_dbg_env(const char* name, int* out) {
+  *out = 0;
+  return getenv(name) ? RF_EINVAL : 0;  // the switch does not exist in this build: say so
+}
+#endif
+
 // environment switches (A/B experiments) are read once per process, not per launch
 static inline bool rf_env_flag(const char* name) { return getenv(name) != nullptr; }
 

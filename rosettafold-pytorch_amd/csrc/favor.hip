@@ -542,7 +542,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
     ob = (int64_t)b * p.o_b + (int64_t)o * p.o_o + h * FV_DH;
   };
   auto ctx_col = [](int tile, int q4) { return ((tile >> 1) * 32 + 8 * q4 + 4 * (tile & 1)) * 2; };
-  const int nch = p.nchunks;
+  const int nch = SOFTMAX ? 1 : p.nchunks;  // (the softmax kernel needs the global key max first: whole sequences only, rf_favor_attention checks)
   int item = blockIdx.x;
   if (item < p.nitems) {
     int64_t xb, ob;
@@ -551,12 +551,16 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
     load_tile8(V_OFF, p.qkv + xb + p.v_off, p.x_s, LS_TAG);
   }
   bool first = true;
-  const bool prof = (p.dbg & 8) && wave == ((p.dbg >> 4) & 7);
+  const bool prof = (RF_DBG(p.dbg) & 8) && wave == ((RF_DBG(p.dbg) >> 4) & 7);  // (false at compile time outside the ablation build)
   unsigned long long acc_cyc[7] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = prof ? __builtin_readcyclecounter() : 0;
   for (; item < p.nitems; item += gridDim.x) {
     int64_t xb, ob;
     item_base(item, xb, ob);
+    // The item's base offsets live in VECTOR registers from here on (opaque copies): as wave-uniform scalars they and the
+    // addresses derived from them stayed in SGPRs across both phases, and the softmax variants -- the most scalar-hungry
+    // ones -- spilled 16-19 SGPRs into VGPR lanes (v_writelane / v_readlane).  The kernel has vector registers to spare.
+    asm volatile("" : "+v"(xb), "+v"(ob));
     if (prof) {
       t_last = __builtin_readcyclecounter();
       acc_cyc[6] += 1;
@@ -613,10 +617,12 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
           if (j < nm) {
-            h16x8 pfj[2];
+            h16x8 pfj[2];  // (swz_off(16 T + fr, c) = 2048 T + swz_off(fr, c): one lane base + an immediate per tile)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) pfj[kk] = *(const h16x8*)(smem + PC_OFF + swz_off((m0t + j) * 16 + frS, kk * 4 + fqS));
-            const bool valid = (m0t + j) * 16 + frS < FV_M;
+            for (int kk = 0; kk < 2; ++kk) pfj[kk] = *(const h16x8*)(smem + PC_OFF + m0t * 2048 + swz_off(frS, kk * 4 + fqS) + j * 2048);
+            // only feature tile 16 (m = 256..271) holds padded features (a per-tile scalar threshold would live in an SGPR for
+            // the whole kernel: the softmax variants spilled them into VGPR lanes)
+            const bool valid = (m0t + j) != FV_MT - 1 || frS < FV_M - 16 * (FV_MT - 1);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
               f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -648,7 +654,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
       }
-      for (int u = hs * NSBH; u < ((p.dbg & 1) ? hs * NSBH : (hs + 1) * NSBH); ++u) {
+      for (int u = hs * NSBH; u < ((RF_DBG(p.dbg) & 1) ? hs * NSBH : (hs + 1) * NSBH); ++u) {
         h16x8 kf[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
           if (j < nm) {
             h16x8 pfj[2];  // re-read per s-block: 8 registers instead of 40 resident ones
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) pfj[kk] = *(const h16x8*)(smem + PC_OFF + swz_off((m0t + j) * 16 + fr, kk * 4 + fq));
+            for (int kk = 0; kk < 2; ++kk) pfj[kk] = *(const h16x8*)(smem + PC_OFF + m0t * 2048 + swz_off(fr, kk * 4 + fq) + j * 2048);
             f32x4 a[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -882,7 +888,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
               num[i][t] = rf_mfma16(cf[i].v, qfr.v, num[i][t], 0, 0, 0);
           }
         };
-        for (int u = 0; u < ((p.dbg & 2) ? 0 : (FV_MT - 1) / 2); ++u) mblock(u, std::false_type{});
+        for (int u = 0; u < ((RF_DBG(p.dbg) & 2) ? 0 : (FV_MT - 1) / 2); ++u) mblock(u, std::false_type{});
         mblock((FV_MT - 1) / 2, std::true_type{});
         FV_STAMP(4)
 #pragma unroll
@@ -923,14 +929,14 @@ static int launch_favor(const FavorAttnP& p, hipStream_t s) {
   const int grid = p.nitems < ncu ? p.nitems : ncu;
   // measured (tools/favor_bench.py): the 8-wave kernel wins for the ReLU features (no AGPR traffic at <= 256
   // registers) and for the softmax features up to 128-row sequences (674 vs 720 us on the MSA-column shape; 9 spilled
-  // registers); at 256 rows the softmax variant spills 59 and stays on the 4-wave kernel.  RF_FAVOR4 / RF_FAVOR8 force one.
-  static const bool force4 = getenv("RF_FAVOR4") != nullptr, force8 = getenv("RF_FAVOR8") != nullptr;
-  const bool use4 = force4 || (SM && LS > 128 && !force8);
-  if (use4) {
+  // registers); at 256 rows the softmax variant does not fit and stays on the 4-wave kernel.  RF_FAVOR4 forces the 4-wave kernel.
+  static const bool force4 = getenv("RF_FAVOR4") != nullptr;
+  constexpr bool only4 = SM && LS > 128;  // (the 8-wave form of this variant does not fit 256 registers: never instantiated)
+  if (only4 || force4) {
     auto k = favor_attention_kernel<LS, SM>;
     if (const int e = rf_enable_big_lds<favor_attention_kernel<LS, SM>>()) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, p);
-  } else {
+  } else if constexpr (!only4) {
     auto k = favor_attention_kernel8<LS, SM>;
     if (const int e = rf_enable_big_lds<favor_attention_kernel8<LS, SM>>()) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, s, p);
@@ -970,7 +976,9 @@ extern "C" int rf_favor_attention(const void* qkv, const void* pc, void* out, co
 #ifdef RF_H16_IS_F16
   for (int n = 1; n < seq_len; n <<= 1) p.ctx_scale *= 0.5f;
 #endif
-  static const int dbg = getenv("RF_FAVOR_DBG") ? atoi(getenv("RF_FAVOR_DBG")) : 0;
+  static int dbg = 0;
+  static const int dbg_rc = rf_dbg_env("RF_FAVOR_DBG", &dbg);
+  if (dbg_rc) return dbg_rc;
   p.dbg = dbg;
   hipStream_t s = (hipStream_t)stream;
   if (ls == 256) return softmax_kernel ? launch_favor<256, true>(p, s) : launch_favor<256, false>(p, s);

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_bf16_kernel(const Gemm
   const int nk = (d.K + BK - 1) / BK;
   // double-buffered DMA: the loads of K step kt+1 are in flight under the MFMAs of step kt
   stage(0);
-  const int nk_run = (p.dbg & 2) ? 1 : nk;
+  const int nk_run = (RF_DBG(p.dbg) & 2) ? 1 : nk;
   for (int kt = 0; kt < nk_run; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_bf16_kernel(const Gemm
 
   if (p.stamps) st2 = __builtin_amdgcn_s_memrealtime();
   // ---- epilogue: lane holds C[m][n..n+3], m = ..+fr, n = ..+4*fq; the bias is already inside the accumulators ----
-  if ((p.dbg & 1) && acc[0][0][0] != 12345.678f) return;
+  if ((RF_DBG(p.dbg) & 1) && acc[0][0][0] != 12345.678f) return;
   const int64_t c_z = z0 * d.c_bs[0] + z1 * d.c_bs[1] + z2 * d.c_bs[2];
   const bool simple = d.act == RF_ACT_NONE || d.act == RF_ACT_RELU || d.act == RF_ACT_BLOCK_LN32;  // branch-free form max(acc * alpha, lo)
   const float lo = d.act == RF_ACT_RELU ? 0.f : -INFINITY;
@@ -707,10 +707,16 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   if (!dd || !dd->A || !dd->B || !dd->C) return RF_EINVAL;
   GemmP p;
   p.d = *dd;
-  p.dbg = (dd->tile_cfg >> 8) & 3;
+  p.dbg = (dd->tile_cfg >> 8) & 3;  // (timing experiments of the tuning build; the production build refuses them)
+#ifndef RF_ABLATION
+  if (p.dbg) return RF_EINVAL;
+#endif
   p.d.tile_cfg &= 0xff;
   rf_gemm_desc& d = p.d;
   if (d.M <= 0 || d.N <= 0 || d.K <= 0) return RF_EINVAL;
+  if (d.rs && (d.ab_dtype != RF_H16 || d.tile_cfg != 0 || d.rs_rpb <= 0 || d.rs_cg <= 0 || d.rs_cg % 16 || d.rs_ncols <= 0 ||
+               d.rs_ncols % d.rs_cg))
+    return RF_EINVAL;
   if (d.nb0 <= 0) d.nb0 = 1;
   if (d.nb1 <= 0) d.nb1 = 1;
   if (d.nb2 <= 0) d.nb2 = 1;
@@ -799,6 +805,7 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
       g_last_family = 4;
       return rc;
     }
+    if (d.rs) return RF_EINVAL;  // the row-group scale lives in the register-resident-weights kernel's epilogue only
     if (rf_gemm_fast_try(d, batch, &rc, stream)) {
       g_last_family = 3;
       return rc;

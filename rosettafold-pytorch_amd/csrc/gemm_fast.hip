@@ -113,14 +113,6 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
   constexpr int NCH = RP * CPRW;
   constexpr int NIT = (NCH + 63) / 64;
   constexpr int G = NIT < 4 ? NIT : 4;  // chunks in flight per lane
-  int soff[NIT], goff[NIT];
-#pragma unroll
-  for (int t = 0; t < NIT; ++t) {
-    const int idx = lane + 64 * t;
-    const int r = idx / CPRW, c = idx % CPRW;
-    soff[t] = r * PITCHW + c * 16;
-    goff[t] = CS ? ((r << 16) | (c * EPC)) : r * p.ldc + c * EPC;  // CS: (strip row, column) pair, resolved per tile
-  }
   auto cs_row = [&](int m) -> int64_t {
     if (p.c_rc <= 0) return (int64_t)m * p.ldc;
     const int q = p.c_rsh >= 0 ? m >> p.c_rsh : m / p.c_rc;
@@ -179,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
     // before the barrier, so the buffer can be re-staged right behind it).
     h16x8 af[WM] = {}, bfr[WN] = {};
     auto read_frags = [&](int kk) {
-      if (p.dbg & 8) return;
+      if (RF_DBG(p.dbg) & 8) return;
       const char* a_lds = smem + buf * STAGE_BYTES;
       const char* b_lds = a_lds + A_BYTES;
 #pragma unroll
@@ -194,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
       }
     };
     auto mfmas = [&]() {
-      if (p.dbg & 1) return;
+      if (RF_DBG(p.dbg) & 1) return;
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -210,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
       __syncthreads();
       if constexpr (STAMP) { const unsigned long long t = clock64(); tk_bar += t - tk_x; tk_x = t; }
       if (kt + 1 < nk) {
-        if (!(p.dbg & 2)) stage(buf ^ 1, m0, n0, kt + 1);
+        if (!(RF_DBG(p.dbg) & 2)) stage(buf ^ 1, m0, n0, kt + 1);
       } else if (has_next)
         stage(buf ^ 1, m0n, n0n, 0);
       const bool second = !(half_tail && kt == nk - 1);
@@ -242,6 +234,20 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
     // ---- epilogue: strips overlay the buffer of the last K step (buf ^ 1 now); buf holds the next tile's step 0 ----
     __syncthreads();  // every wave is done reading that buffer
     if constexpr (!LN) {
+      // strip / global offsets of this lane's chunks, rebuilt per tile from an opaque copy of the lane id: computed once
+      // before the tile loop they stay live through the K loop, which has no registers to spare at BN = 288 (29 spilled)
+      int soff[NIT], goff[NIT];
+      {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+          const int idx = ln + 64 * t;
+          const int r = idx / CPRW, c = idx % CPRW;
+          soff[t] = r * PITCHW + c * 16;
+          goff[t] = CS ? ((r << 16) | (c * EPC)) : r * p.ldc + c * EPC;  // CS: (strip row, column) pair, resolved per tile
+        }
+      }
       constexpr int WSTRIDE = RP * PITCHW;
       char* const strip = smem + (buf ^ 1) * STAGE_BYTES + wave * WSTRIDE;
       char* const Cw = (char*)p.C + ((int64_t)(m0 + wm * TM) * p.ldc + n0 + wn * TN) * ESZ;
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
           for (int g = 0; g < G; ++g) {
             if constexpr (HAS_RES) {
               res[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-              if (t0 + g < NIT && (NCH % 64 == 0 || lane + 64 * (t0 + g) < NCH) && !(p.dbg & 4)) res[g] = *(const f32x4*)(Rp + (unsigned)goff[t0 + g] * 4u);
+              if (t0 + g < NIT && (NCH % 64 == 0 || lane + 64 * (t0 + g) < NCH) && !(RF_DBG(p.dbg) & 4)) res[g] = *(const f32x4*)(Rp + (unsigned)goff[t0 + g] * 4u);
             }
           }
 #pragma unroll
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
             } else {
               dst = (f32x4*)(Cp + (unsigned)goff[t0 + g] * (unsigned)ESZ);
             }
-            if (p.dbg & 4) continue;
+            if (RF_DBG(p.dbg) & 4) continue;
             if (p.nt_store)
               __builtin_nontemporal_store(v, dst);
             else
@@ -343,80 +349,80 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
       // Fused "LayerNorm of the next sub-layer" (N == BN: the tile spans whole rows).  Per pass of 8 rows a wave moves its
       // accumulator rows through its private strip into a ROW-CONTIGUOUS register image -- lane (r = lane / 8, c8 = lane % 8)
       // holds the 16-byte pieces c8, c8 + 8, ... of row r -- adds the fp32 residual there (whole 128-byte lines per row and
-      // instruction, as the plain epilogue), stores the updated stream and keeps it in registers (they replace the dying
-      // accumulators one for one).  Half-row sums / sums of squares (three shuffles over the row's 8 lanes) meet the other
-      // wave column's in LDS behind ONE barrier per tile; then the rows are normalised in registers and leave as 16-bit
-      // pieces.  The separate LayerNorm launch and its re-read of the stream disappear (10.6 % of the round-2 step).
+      // instruction, as the plain epilogue) and stores the updated stream.  The half-row sums / sums of squares (three
+      // shuffles over the row's 8 lanes) meet the other wave column's in LDS behind a raw workgroup barrier (LDS traffic
+      // only: the stores just issued and the next tile's operand DMA stay in flight), then the pass's rows are normalised in
+      // registers and leave as 16-bit pieces.  Nothing but the pass's 5-6 pieces per lane is kept: no register image of the
+      // whole tile (a first version that kept one and synchronised once per tile spilled 164 registers and lost more than the
+      // LayerNorm launch costs).  The separate LayerNorm launch and its re-read of the stream disappear.
       constexpr int RPL = 8, NPASS = TM / RPL, CPR = TN / 4, KCH = (CPR + 7) / 8;
       static_assert(NW * RPL * PITCHW <= 56 * 1024 && 56 * 1024 + BM * 16 <= STAGE_BYTES, "strips / row statistics do not fit a stage buffer");
       char* const strip = smem + (buf ^ 1) * STAGE_BYTES + wave * (RPL * PITCHW);
       float2* const hst = (float2*)(smem + (buf ^ 1) * STAGE_BYTES + 56 * 1024);  // [BM rows][2 wave columns] (sum, sum of squares)
-      const int r = lane >> 3, c8 = lane & 7;
+      int ln = lane, frl = fr, fql = fq;  // opaque copies: everything derived from them is rebuilt here, per tile, instead of being
+      asm volatile("" : "+v"(ln), "+v"(frl), "+v"(fql));  // hoisted out of the tile loop into registers the K loop has none of
+      const int r = ln >> 3, c8 = ln & 7;
       char* const Cw = (char*)p.C + ((int64_t)(m0 + wm * TM + r) * p.ldc + n0 + wn * TN) * 4;
       const char* const Rw = (const char*)p.residual + ((int64_t)(m0 + wm * TM + r) * p.ldc + n0 + wn * TN) * 4;
-      f32x4 v[NPASS][KCH];
+      const float* const gam = (const float*)(smem + GB_OFF) + wn * TN;
+      h16_t* const Lw = (h16_t*)p.ln_out + (int64_t)(m0 + wm * TM + r) * BN + wn * TN;
 #pragma unroll
       for (int ps = 0; ps < NPASS; ++ps) {
         const int r0 = ps * RPL, i = r0 / 16;
-        if ((fr >> 3) == ((r0 >> 3) & 1)) {
-          char* lrow = strip + (fr & 7) * PITCHW;
+        if ((frl >> 3) == ((r0 >> 3) & 1)) {
+          char* lrow = strip + (frl & 7) * PITCHW;
 #pragma unroll
-          for (int j = 0; j < WN; ++j) *(f32x4*)(lrow + (j * 16 + 4 * fq) * 4) = acc[i][j];
+          for (int j = 0; j < WN; ++j) *(f32x4*)(lrow + (j * 16 + 4 * fql) * 4) = acc[i][j];
         }
         asm volatile("" ::: "memory");  // (keeps the strip reads below out of the lane-masked write block)
-        f32x4 res[KCH];
+        f32x4 v[KCH];
 #pragma unroll
         for (int k = 0; k < KCH; ++k) {
-          res[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if (CPR % 8 == 0 || k < KCH - 1 || c8 + 8 * k < CPR)
-            res[k] = *(const f32x4*)(Rw + ((int64_t)r0 * p.ldc + (c8 + 8 * k) * 4) * 4);
+            v[k] = *(const f32x4*)(Rw + ((int64_t)r0 * p.ldc + (c8 + 8 * k) * 4) * 4);
         }
         float sm = 0.f, sq = 0.f;
 #pragma unroll
         for (int k = 0; k < KCH; ++k) {
-          const bool ok = CPR % 8 == 0 || k < KCH - 1 || c8 + 8 * k < CPR;
-          f32x4 x = (f32x4){0.f, 0.f, 0.f, 0.f};
-          if (ok) {
-            x = *(const f32x4*)(strip + r * PITCHW + (c8 + 8 * k) * 16) + res[k];
+          if (CPR % 8 == 0 || k < KCH - 1 || c8 + 8 * k < CPR) {
+            const f32x4 x = *(const f32x4*)(strip + r * PITCHW + (c8 + 8 * k) * 16) + v[k];
             f32x4* dst = (f32x4*)(Cw + ((int64_t)r0 * p.ldc + (c8 + 8 * k) * 4) * 4);
             if (p.nt_store)
               __builtin_nontemporal_store(x, dst);
             else
               *dst = x;
+            v[k] = x;
+            sm += (x[0] + x[1]) + (x[2] + x[3]);
+            sq += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
           }
-          v[ps][k] = x;
-          sm += (x[0] + x[1]) + (x[2] + x[3]);
-          sq += (x[0] * x[0] + x[1] * x[1]) + (x[2] * x[2] + x[3] * x[3]);
         }
 #pragma unroll
         for (int o = 1; o <= 4; o <<= 1) {
           sm += __shfl_xor(sm, o, 64);
           sq += __shfl_xor(sq, o, 64);
         }
-        if (c8 == 0) hst[(wm * TM + r0 + r) * 2 + wn] = make_float2(sm, sq);
+        const int row = wm * TM + r0 + r;
+        if (c8 == 0) hst[row * 2 + wn] = make_float2(sm, sq);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // both wave columns' half-row sums of this pass are in place
         asm volatile("" ::: "memory");
-      }
-      __syncthreads();  // both wave columns' half-row sums are in place
-      const float* const gam = (const float*)(smem + GB_OFF) + wn * TN;
-      h16_t* const Lw = (h16_t*)p.ln_out + (int64_t)(m0 + wm * TM + r) * BN + wn * TN;
-#pragma unroll
-      for (int ps = 0; ps < NPASS; ++ps) {
-        const int row = wm * TM + ps * RPL + r;
-        const float2 ha = hst[row * 2], hb = hst[row * 2 + 1];
-        const float mean = (ha.x + hb.x) * (1.0f / BN);
-        const float rstd = rsqrtf(fmaxf((ha.y + hb.y) * (1.0f / BN) - mean * mean, 0.f) + p.ln_eps);
+        const float2 hb = hst[row * 2 + (wn ^ 1)];
+        const float mean = (sm + hb.x) * (1.0f / BN);
+        const float rstd = rsqrtf(fmaxf((sq + hb.y) * (1.0f / BN) - mean * mean, 0.f) + p.ln_eps);
 #pragma unroll
         for (int k = 0; k < KCH; ++k) {
           if (CPR % 8 == 0 || k < KCH - 1 || c8 + 8 * k < CPR) {
             const int c = (c8 + 8 * k) * 4;
             const f32x4 g4 = *(const f32x4*)(gam + c), b4 = *(const f32x4*)(gam + BN + c);
-            const f32x4 o = (v[ps][k] - mean) * rstd * g4 + b4;
+            const f32x4 o = (v[k] - mean) * rstd * g4 + b4;
             uint2 w;
             w.x = rf_pack2_h16(o[0], o[1]);
             w.y = rf_pack2_h16(o[2], o[3]);
-            *(uint2*)(Lw + (int64_t)(ps * RPL) * BN + c) = w;
+            *(uint2*)(Lw + (int64_t)r0 * BN + c) = w;
           }
         }
+        asm volatile("" ::: "memory");
       }
     }
     if constexpr (STAMP) {
@@ -503,7 +509,9 @@ int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
   const bool f32 = d.c_dtype == RF_F32, res = d.residual != nullptr;
   p.stamps = g_fast_stamps;
   p.no_lag = no_lag;
-  static const int dbg = getenv("RF_GEMM_DBG") ? atoi(getenv("RF_GEMM_DBG")) : 0;
+  static int dbg = 0;
+  static const int dbg_rc = rf_dbg_env("RF_GEMM_DBG", &dbg);
+  if (dbg_rc) { *rc = dbg_rc; return 1; }
   p.dbg = dbg;
   p.ln_out = d.ln_out; p.ln_gamma = d.ln_gamma; p.ln_beta = d.ln_beta; p.ln_eps = d.ln_eps;
   p.c_rc = d.c_rc; p.c_cc = d.c_cc; p.c_ro = d.c_ro; p.c_co = d.c_co;

@@ -37,6 +37,11 @@ struct WregP {
   int nt_store;
   int c_rc, c_cc, c_rsh, c_csh;
   int64_t c_ro, c_co;
+  // row-group scale of the leading rs_ncols columns (rf_gemm_desc.rs): the tied-attention position weights folded into q
+  const float* rs;
+  int64_t rs_bstride;
+  int rs_rpb, rs_cg, rs_ncols;
+  float rs_alpha;
 };
 
 __device__ __forceinline__ void wreg_glds16(const void* src, void* lds_wave_base) {
@@ -186,6 +191,22 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(const WregP p) {
             acc[i][j] = rf_mfma16(wf[j][s], af[i], acc[i][j], 0, 0, 0);
       }
     }
+    if (p.rs && n0 < p.rs_ncols) {  // (wave-uniform; rs_cg % 16 == 0: a 16-column tile lies inside one column group)
+#pragma unroll
+      for (int i = 0; i < WRT; ++i) {
+        const int m = mt * TMR + wr * (16 * WRT) + i * 16 + fr;
+        const int qb = m / p.rs_rpb;
+        const float* rsm = p.rs + (int64_t)qb * p.rs_bstride + (m - qb * p.rs_rpb);
+#pragma unroll
+        for (int j = 0; j < WCT; ++j) {
+          const int n = n0 + j * 16;
+          if (n < p.rs_ncols) {
+            const float sc = rsm[(int64_t)(n / p.rs_cg) * p.rs_rpb] * p.rs_alpha;
+            acc[i][j] *= sc;
+          }
+        }
+      }
+    }
     // ---- epilogue: wave-private strip (in-order LDS per wave: no barrier), 16-byte row-contiguous stores -----------
     const float lo = p.relu ? 0.f : -INFINITY;
 #pragma unroll
@@ -270,6 +291,7 @@ int rf_gemm_wreg_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
   p.c_rc = d.c_rc; p.c_cc = d.c_cc; p.c_ro = d.c_ro; p.c_co = d.c_co;
   p.c_rsh = (d.c_rc > 0 && (d.c_rc & (d.c_rc - 1)) == 0) ? __builtin_ctz(d.c_rc) : -1;
   p.c_csh = (d.c_cc > 0 && (d.c_cc & (d.c_cc - 1)) == 0) ? __builtin_ctz(d.c_cc) : -1;
+  p.rs = d.rs; p.rs_bstride = d.rs_bstride; p.rs_rpb = d.rs_rpb; p.rs_cg = d.rs_cg; p.rs_ncols = d.rs_ncols; p.rs_alpha = d.rs_alpha;
   hipStream_t s = (hipStream_t)stream;
   const bool wide = d.N % 256 == 0 && force != 2;
   if (d.N % 384 == 0 && (force == 0 || force == 3)) {

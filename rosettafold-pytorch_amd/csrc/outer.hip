@@ -29,7 +29,7 @@
 struct OuterP {
   const h16_t* xt;   // [B, L, 32, N]   x_t[b,i,u,n]  (MSA depth contiguous)
   const h16_t* yt;   // [B, L, 32, N]
-  const h16_t* wp;   // [Dout, 1024]    W * gamma
+  const h16_t* wp;   // [16, Dout, 64]  W * gamma, chunk-major: wp[c][o][uu * 8 + vv] = (W gamma)[o][(8 (c / 4) + uu) * 32 + 8 (c % 4) + vv]
   const float* s;    // [Dout]          row sums of wp
   const float* c;    // [Dout]          W beta + bias
   float* out;        // [B, L, L, Dout] fp32
@@ -97,7 +97,11 @@ __global__ __launch_bounds__(512, 2) void outer_fused_kernel(const OuterP p) {
 
   // stage-2 constants of this wave: main columns o = 32 wave + 16 cc + 4 fq .. +3
   const int o_w = wave * 32;
-  const h16_t* const wrow = p.wp + (int64_t)(o_w + fr) * 1024 + fq * 32;  // + cc * 16 rows + (8 ug + 4 s2) * 32 + 8 vg
+  // W' is stored CHUNK-MAJOR, [16 chunks][Dout][64 features of the chunk] (ops.outer_fold): the 64 features a chunk contracts
+  // over are one 128-byte line per output column, so a fragment load touches 16 lines of 64 useful bytes.  (Round 2 kept the
+  // nn.Linear layout [Dout][1024], where those features are eight 16-byte runs 64 bytes apart: every load instruction
+  // fetched 64 separate L2 sectors for 1 KB of fragments, 4096 L2 requests per CU and chunk -- the kernel's real bound.)
+  const h16_t* const wrow = p.wp + (int64_t)(o_w + fr) * 64 + fq * 8;  // + (c * Dout + cc * 16) * 64 + s2 * 32
 
   // stage-1 geometry of this wave: y row tile art (rows = (j, v)), x column tiles bct0 .. bct0 + 3 (cols = (i, u))
   const int art = wave & 3, bct0 = (wave >> 2) * 4;
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void outer_fused_kernel(const OuterP p) {
                    __builtin_amdgcn_readfirstlane(dst + q * 1024));
     }
   };
-  // extra-column W' slice of chunk c: rows o = 256 + r (r < 32), features (8 ug + uu) * 32 + 8 vg .. + 7 for uu < 8: one
+  // extra-column W' slice of chunk c: rows o = 256 + r (r < 32), 4 KB of contiguous memory in the chunk-major layout: one
   // instruction = 8 rows x 8 slots; waves 0-3 issue one each (the slice is the same for every tile: L2-resident)
   auto dma_wx = [&](int c) {
     if (wave < 4) {
@@ -174,12 +178,12 @@ __global__ __launch_bounds__(512, 2) void outer_fused_kernel(const OuterP p) {
       asm volatile("" : "+v"(ln));
       const int row = wave * 8 + (ln >> 3), sl = ln & 7;
       const int uu = sl ^ ((row >> 1) & 7);
-      outer_glds16(p.wp + (int64_t)(256 + row) * 1024 + (8 * (c >> 2) + uu) * 32 + 8 * (c & 3),
+      outer_glds16(p.wp + ((int64_t)c * 288 + 256 + row) * 64 + uu * 8,
                    __builtin_amdgcn_readfirstlane(lds0 + WX_OFF + (c & 1) * WXB + wave * 1024));
     }
   };
   auto wload = [&](int c, int s2, int cc) {
-    return *(const h16x8*)(wrow + cc * 16 * 1024 + (8 * (c >> 2) + 4 * s2) * 32 + 8 * (c & 3));
+    return *(const h16x8*)(wrow + ((int64_t)c * 288 + cc * 16) * 64 + s2 * 32);
   };
 
   // main W' fragments of two consecutive chunks: [s2][cc]; set A serves even chunks, set B odd ones

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void tied_logits_kernel(const TiedP p) {
   const int64_t lane_off = (int64_t)lrow * p.l_stride + c_log * 8;
   auto stage = [&](int n) {
     char* st = smem + (n % NSTG) * STAGE;
-    const bool live = n < p.N && !((p.dbg & 1) && n >= NSTG - 1);
+    const bool live = n < p.N && !((RF_DBG(p.dbg) & 1) && n >= NSTG - 1);
 #pragma unroll
     for (int t = 0; t < PW; ++t) {
       const int instr = t * 4 + wave;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void tied_logits_kernel(const TiedP p) {
     const char* st = smem + (n % NSTG) * STAGE;
     TFrag qf;
     h16x8 kf[JT];
-    if (!(p.dbg & 2) || n == 0) {
+    if (!(RF_DBG(p.dbg) & 2) || n == 0) {
       qf.v = *(const h16x8*)(st + q_rd);
 #pragma unroll
       for (int j = 0; j < JT; ++j) kf[j] = *(const h16x8*)(st + k_rd + j * 1024);
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void tied_logits_kernel(const TiedP p) {
       for (int e = 0; e < 4; ++e)
         qf.u[e] = tpack2(rf_h16_lo(qf.u[e]) * ws, rf_h16_hi(qf.u[e]) * ws);
     }
-    if (!(p.dbg & 4)) {
+    if (!(RF_DBG(p.dbg) & 4)) {
 #pragma unroll
       for (int j = 0; j < JT; ++j)
         // key tile as MFMA-A, query tile as MFMA-B: lane holds logits[i = fr][j = 16*tile + 4*fq .. +3]
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(512) void tied_logits_split_kernel(const TiedSplitP
     const char* st = smem + (t_ % NSTG) * STAGE;
     TFrag qf[4];
     h16x8 kf[4];
-    if (!(p.dbg & 2) || t_ == 0) {
+    if (!(RF_DBG(p.dbg) & 2) || t_ == 0) {
 #pragma unroll
       for (int qt = 0; qt < 4; ++qt) qf[qt].v = *(const h16x8*)(st + q_rd + qt * 1024);
 #pragma unroll
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(512) void tied_logits_split_kernel(const TiedSplitP
           qf[qt].u[e] = tpack2(rf_h16_lo(qf[qt].u[e]) * ws, rf_h16_hi(qf[qt].u[e]) * ws);
       }
     }
-    if (!(p.dbg & 4)) {
+    if (!(RF_DBG(p.dbg) & 4)) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(512) void tied_logits_split_kernel(const TiedSplitP
           acc[kt][qt] = rf_mfma16(kf[kt], qf[qt].v, acc[kt][qt], 0, 0, 0);
     }
   }
-  if (p.dbg & 8) return;
+  if (RF_DBG(p.dbg) & 8) return;
   // partial logits: 16-byte pieces, the four lanes of a row group cover 64 contiguous bytes, a wave's four key tiles 256
   float* pr = p.part + (int64_t)sp * p.split_stride + (((int64_t)b * p.H + h) * L + rb * RB + wr * 64 + fr) * L + wc * 64 + 4 * fq;
 #pragma unroll
@@ -346,9 +346,10 @@ __global__ __launch_bounds__(256) void tied_att_sym_kernel(const h16_t* att, flo
   }
 }
 
-static int tied_dbg() {
-  static const int v = getenv("RF_TIED_DBG") ? atoi(getenv("RF_TIED_DBG")) : 0;
-  return v;
+static int tied_dbg() {  // < 0: the switch is set but this build has no ablation code (RF_EINVAL)
+  static int v = 0;
+  static const int rc = rf_dbg_env("RF_TIED_DBG", &v);
+  return rc ? rc : v;
 }
 
 template <int L, bool SCALE>
@@ -424,6 +425,7 @@ extern "C" int rf_tied_logits_softmax(const void* q, const void* k, int64_t b_st
   p.w = nullptr; p.w_b = p.w_h = p.w_n = 0; p.qscale = 1.f;
   p.att = (h16_t*)att; p.B = B; p.H = H; p.N = N;
   p.dbg = tied_dbg();
+  if (p.dbg < 0) return p.dbg;
   hipStream_t s = (hipStream_t)stream;
   const int rc = tied_logits_dispatch(p, L, s);
   if (rc != 0 || !att_sym) return rc;
@@ -632,6 +634,7 @@ extern "C" int rf_tied_attention(const void* q, const void* k, const void* v, co
   p.qscale = qscale;
   p.att = (h16_t*)att; p.B = B; p.H = H; p.N = N;
   p.dbg = tied_dbg();
+  if (p.dbg < 0) return p.dbg;
   hipStream_t s = (hipStream_t)stream;
   int rc = tied_logits_split(p, L, partial_ws, partial_ws_elems, s);
   if (rc == 1) rc = tied_logits_dispatch(p, L, s);

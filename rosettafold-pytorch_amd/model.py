@@ -42,6 +42,7 @@ class _Runtime:
     fused_tied = not bool(int(__import__("os").environ.get("RF_NO_FUSED_TIED", "0")))  # tied-attention logits + softmax in one launch
     fused_outer = not bool(int(__import__("os").environ.get("RF_NO_FUSED_OUTER", "0")))  # outer product -> LN -> Linear in one kernel
     tied_v2 = not bool(int(__import__("os").environ.get("RF_TIED_V1", "0")))  # head-major q|k|v + collapsed weights + A.V kernel
+    tied_fold_w = not bool(int(__import__("os").environ.get("RF_TIED_NO_FOLD", "0")))  # position weights folded into q by the projection's epilogue
     head_major_qkv = bool(int(__import__("os").environ.get("RF_HEAD_MAJOR_QKV", "0")))
     # Producer -> consumer chains whose intermediate (q|k|v, feed-forward hidden) is larger than this many bytes are run
     # panel by panel, so the intermediate panel is still in the 256 MB Infinity Cache when its consumer reads it
@@ -518,9 +519,6 @@ class SoftTiedAttentionOverResidues(RFModule):
         pw = self.poswise_weight
         G = 3 * H
         lins = [self.to_q, self.to_k, self.to_v]
-        qkv = torch.empty(B, N, G, Lr, dh, device=dev, dtype=T())
-        ops.gemm(xn, self.wcat("qkv", lins), qkv, B * N * Lr, 3 * D, D, bias=self.bcat("qkv", lins),
-                 c_row=(Lr, G * Lr * dh, dh), c_col=(dh, Lr * dh))
         # u[b,l,h,:] = W_k[h*dh:(h+1)*dh, :]^T to_q(x_0)[b,l,h*dh:(h+1)*dh]   (rf.py:205-217, collapsed)
         q0 = pw.query_proj(xn)
         wkt = pw.cached("wkT", lambda: pw.to_k[0].weight.detach().t().contiguous().to(T()))
@@ -528,11 +526,18 @@ class SoftTiedAttentionOverResidues(RFModule):
         ops.gemm(q0, wkt, u, B * Lr, D, dh, batch=(H, 1, 1), a_bs=(dh, 0, 0), a_row=(0, 0, D), b_bs=(dh, 0, 0),
                  b_row=(0, 0, D), c_bs=(D, 0, 0), c_row=(0, 0, H * D))
         w = ops.poswise_collapsed(xn, u, pw.scale)  # fp32 [B,H,N,L]
+        qkv = torch.empty(B, N, G, Lr, dh, device=dev, dtype=T())
+        # q * w * d_head^-0.5 (rf.py:252) in the projection's epilogue, on the fp32 accumulators: q is rounded once, after
+        # the scaling, and the logits kernel neither stages the weights nor rescales its fragments (round 2: 15-20 us of VALU)
+        fold = RT.tied_fold_w and D in (288, 384) and dh % 16 == 0
+        ops.gemm(xn, self.wcat("qkv", lins), qkv, B * N * Lr, 3 * D, D, bias=self.bcat("qkv", lins),
+                 c_row=(Lr, G * Lr * dh, dh), c_col=(dh, Lr * dh),
+                 rs=(w, H * N * Lr, N * Lr, dh, D, self.scale) if fold else None)
         att = torch.empty(B, H, Lr, Lr, device=dev, dtype=T())
         att_sym = torch.empty(B, Lr, Lr, H, device=dev, dtype=F32) if want_att else None
         out = torch.empty(B, N, Lr, D, device=dev, dtype=T())
         ops.tied_attention(qkv[:, :, 0:H], qkv[:, :, H:2 * H], qkv[:, :, 2 * H:], out.view(B, N, Lr, H, dh).permute(0, 1, 3, 2, 4),
-                           att, w=w, qscale=self.scale, att_sym=att_sym)
+                           att, w=None if fold else w, qscale=1.0 if fold else self.scale, att_sym=att_sym)
         xn_next = ops.linear_residual_ln(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln)
         return att_sym, xn_next
 

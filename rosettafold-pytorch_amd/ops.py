@@ -80,7 +80,7 @@ def gemm(A, B, Cout, M, N, K, *, batch=(1, 1, 1), a_off=0, b_off=0, c_off=0,
          b_bs=(0, 0, 0), b_row=(0, 0, None), b_ko=0, kc=0,
          c_bs=(0, 0, 0), c_row=(0, 0, None), c_col=(0, 0),
          bias=None, bias_mode=None, act=L.ACT_NONE, act_nvalid=0, act_eps=0.0, alpha=1.0,
-         residual=None, res_off=None, conv=None, tile_cfg=0, ln=None, block_ln=None):
+         residual=None, res_off=None, conv=None, tile_cfg=0, ln=None, block_ln=None, rs=None):
     """C = epilogue(alpha * A @ B^T) with the strided/batched/chunked addressing of rf_gemm_desc.
     *_row = (rc, ro, ri): offset(m) = (m // rc)*ro + (m % rc)*ri, rc=0 -> m*ri.  ri=None -> K (A,B) / N (C).
     c_col = (cc, co).  Offsets are in elements.  conv = (n, h, w, c, dilation) selects implicit 3x3 im2col."""
@@ -120,6 +120,12 @@ def gemm(A, B, Cout, M, N, K, *, batch=(1, 1, 1), a_off=0, b_off=0, c_off=0,
         g, b, eps = block_ln
         _need_cuda(g, b)
         d.ln_gamma, d.ln_beta, d.ln_eps = g.data_ptr(), b.data_ptr(), float(eps)
+    if rs is not None:  # (scale fp32, bstride, rpb, cg, ncols, alpha): row-group scale of the leading columns (rf_gemm_desc.rs)
+        t_, bstride, rpb, cg, ncols, alpha_ = rs
+        _need_cuda(t_)
+        if t_.dtype != F32:
+            raise TypeError("rs must be fp32")
+        d.rs, d.rs_bstride, d.rs_rpb, d.rs_cg, d.rs_ncols, d.rs_alpha = t_.data_ptr(), int(bstride), int(rpb), int(cg), int(ncols), float(alpha_)
     if ln is not None:  # (out bf16 [M,N], gamma, beta, eps): fused LayerNorm of the result rows
         ln_out, g, b, eps = ln
         _need_cuda(ln_out, g, b)
@@ -226,7 +232,8 @@ def tied_row_attention(q, k, v):
 
 
 def outer_fused(xt, yt, wprime, s, c, out, eps, ln2=None):
-    """Fused OuterProductMean core (csrc/outer.hip): xt, yt bf16 [B, L, 32, N]; wprime bf16 [Dout, 1024]; out fp32 [B,L,L,Dout].
+    """Fused OuterProductMean core (csrc/outer.hip): xt, yt bf16 [B, L, 32, N]; wprime bf16 [16, Dout, 64] (outer_fold's chunk-major
+    layout); out fp32 [B,L,L,Dout].
     ln2 = (gamma, beta, eps, y, y_ld): also apply LayerNorm over Dout and write bf16 y[(b,i,j) * y_ld + o] instead of `out`."""
     B, L_, P, N = xt.shape
     _need_cuda(xt, yt, wprime, s, c, out)
@@ -235,7 +242,9 @@ def outer_fused(xt, yt, wprime, s, c, out, eps, ln2=None):
     if ln2 is not None:
         g2, b2, eps2, y, y_ld = ln2
         _need_cuda(g2, b2, y)
-    check(lib.rf_outer_product_ln_linear(ptr(xt), ptr(yt), ptr(wprime), ptr(s), ptr(c), ptr(out), B, L_, N, P, wprime.shape[0],
+    if wprime.dim() != 3 or wprime.shape[0] != 16 or wprime.shape[2] != 64:
+        raise ValueError("outer_fused: wprime must come from outer_fold (chunk-major [16, Dout, 64])")
+    check(lib.rf_outer_product_ln_linear(ptr(xt), ptr(yt), ptr(wprime), ptr(s), ptr(c), ptr(out), B, L_, N, P, wprime.shape[1],
                                          float(eps), ptr(g2), ptr(b2), float(eps2), ptr(y), int(y_ld), stream()),
           "rf_outer_product_ln_linear")
     return y if ln2 is not None else out
@@ -244,7 +253,12 @@ def outer_fused(xt, yt, wprime, s, c, out, eps, ln2=None):
 def outer_fold(w, gamma, beta, bias, dtype=None):
     """(W * gamma in the 16-bit type, its fp32 row sums, W beta + bias): the LayerNorm(1024) affine folded into Linear(1024 -> Dout)."""
     wp = (w.float() * gamma.float()[None, :]).to(dtype or h16()).contiguous()
-    return wp, wp.float().sum(1).contiguous(), (w.float() @ beta.float() + bias.float()).contiguous()
+    s = wp.float().sum(1).contiguous()
+    # kernel layout: chunk-major [16 chunks = (ug, vg)][Dout][64 = (uu, vv)] with feature k = (8 ug + uu) * 32 + 8 vg + vv: the 64
+    # features a chunk of the fused kernel contracts over are one 128-byte line per output column (csrc/outer.hip)
+    Dout = wp.shape[0]
+    wpc = wp.view(Dout, 4, 8, 4, 8).permute(1, 3, 0, 2, 4).contiguous().view(16, Dout, 64)
+    return wpc, s, (w.float() @ beta.float() + bias.float()).contiguous()
 
 
 def outer_product_ln_linear(x, y, gamma, beta, w, b, eps):
@@ -555,12 +569,13 @@ def favor_attention(qkv, pc, out, x_strides, o_strides, q_off, k_off, v_off, n_b
     return out
 
 
-# Measured on MI355X (tools/ln_fuse_bench.py): the fused epilogue costs more than residual GEMM + the vectorised
-# rf_layernorm (0.50 vs 0.37 ms at M=262144, N=288, K=512), so it is opt-in.
-FUSE_LN = False
-# fused residual + next-LayerNorm epilogue of the persistent GEMM for the 288-wide pair rows: correct, but measured
-# slower than GEMM + the vectorised LayerNorm launch (444 vs 213 + 95 us per sub-layer), so opt-in
-FUSE_LN_288 = bool(int(__import__("os").environ.get("RF_FUSED_LN", "0")))
+# Fused residual + next-LayerNorm epilogue of the persistent GEMM (csrc/gemm_fast.hip, round 3: row-contiguous register image,
+# one barrier per tile): the 288-wide pair rows (256 x 288 tiles) and the 384-wide MSA rows (128 x 384 tiles).  RF_NO_FUSED_LN=1
+# restores the separate rf_layernorm launch for A/B timing.
+FUSE_LN = not bool(int(__import__("os").environ.get("RF_NO_FUSED_LN", "0")))
+# the generic tile kernel's fused form (any N <= 384 whose rows fit one tile; slower than GEMM + rf_layernorm on the forward's
+# shapes, so opt-in: tests/test_kernels_gpu.py exercises it)
+FUSE_LN_ANY = False
 
 
 def linear_residual_ln(x, w, bias, x_res, next_ln):
@@ -568,9 +583,10 @@ def linear_residual_ln(x, w, bias, x_res, next_ln):
     (bf16 operands, full rows per tile), also returns LayerNorm_next(x_res) in bf16; otherwise returns None and the
     caller normalises with rf_layernorm."""
     N = w.shape[0]
-    # N == 288 with whole 256-row panels: the persistent GEMM normalises the rows in its epilogue (csrc/gemm_fast.hip)
-    fused = FUSE_LN or (FUSE_LN_288 and N == 288 and (x_res.numel() // N) % 256 == 0 and (x_res.numel() // N) >= 16384)
-    if fused and next_ln is not None and is_h16(x.dtype) and N <= 384 and N % 4 == 0 and x_res.is_contiguous():
+    rows = x_res.numel() // N
+    # whole rows per tile: the persistent GEMM normalises the updated rows in its epilogue (csrc/gemm_fast.hip)
+    fused = (FUSE_LN and N in (288, 384) and rows % 256 == 0 and rows >= 16384) or (FUSE_LN_ANY and N <= 384 and N % 4 == 0)
+    if fused and next_ln is not None and is_h16(x.dtype) and x_res.is_contiguous() and x.is_contiguous():
         xn = torch.empty(x_res.shape, device=x_res.device, dtype=x.dtype)
         linear(x, w, bias, out=x_res, residual=x_res,
                ln=(xn, next_ln.weight.detach(), next_ln.bias.detach(), next_ln.eps))

@@ -55,7 +55,7 @@ def test_gemm_desc_layout_matches_c():
     """compile a tiny C program printing sizeof/offsetof of rf_gemm_desc and compare with the ctypes mirror."""
     from rosettafold_pytorch_amd._lib import GemmDesc
     fields = ["M", "kc", "a_bs", "a_ko", "b_bs", "c_bs", "c_co", "conv_n", "bias_mode", "act_eps", "alpha", "tile_cfg",
-              "A", "bias", "residual", "ln_out", "ln_eps"]
+              "A", "bias", "residual", "ln_out", "ln_eps", "rs", "rs_bstride", "rs_rpb", "rs_alpha"]
     prog = '#include <stdio.h>\n#include <stddef.h>\n#include "rfmi.h"\nint main(){printf("%zu", sizeof(rf_gemm_desc));' + \
            "".join(f'printf(" %zu", offsetof(rf_gemm_desc, {f}));' for f in fields) + "return 0;}"
     exe = "/tmp/rf_layout_check"

@@ -32,7 +32,7 @@ import depth_parity as DP  # noqa: E402
 
 
 class _Args:
-    oracle, struct_lowp, modes, N, L, n_two, n_three = True, False, "fp32,fp16,bf16", 128, 256, 2, 2
+    oracle, struct_lowp, modes, B, N, L, n_two, n_three = True, False, "fp32,fp16,bf16", 1, 128, 256, 2, 2
 
 
 @pytest.fixture(scope="module")

@@ -115,34 +115,45 @@ def test_gemm_persistent_exact_integers():
         assert torch.equal(y.float(), x.float() @ w.float().t())
 
 
-@pytest.mark.parametrize("K", [512, 288, 1152])
-def test_gemm_persistent_fused_layernorm(K):
-    """N = 288 residual GEMM over whole 256-row panels: the persistent kernel adds the residual, writes the fp32 rows and
-    emits LayerNorm_next(rows) in bf16 from the same epilogue (no second launch)."""
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("N,K", [(288, 512), (288, 288), (288, 1152), (384, 384), (384, 768), (384, 1536)])
+def test_gemm_persistent_fused_layernorm(N, K, dt):
+    """Residual GEMM over whole-row tiles (288-wide pair rows: 256 x 288 tiles; 384-wide MSA rows: 128 x 384 tiles): the
+    persistent kernel adds the residual, writes the fp32 rows and emits LayerNorm_next(rows) in the 16-bit type from the same
+    epilogue (no second launch) -- the form the forward uses (ops.linear_residual_ln), in both 16-bit builds."""
     import torch.nn as nn
-    M, N = 32768, 288
-    x, w, b = randn(M, K, dtype=torch.bfloat16), randn(N, K, dtype=torch.bfloat16, seed=1) * 0.1, randn(N, seed=2)
-    res = randn(M, N, seed=3) * 2 + 0.5
-    lnm = nn.LayerNorm(N).to(DEV)
-    with torch.no_grad():
-        lnm.weight.copy_(randn(N, seed=4)); lnm.bias.copy_(randn(N, seed=5))
-    ref = res + x.float() @ w.float().t() + b
-    ref_ln = torch.nn.functional.layer_norm(ref, (N,), lnm.weight, lnm.bias, lnm.eps)
-    out = res.clone()
-    ops.FUSE_LN_288 = True
+    import rosettafold_pytorch_amd as R
+    R.set_compute_dtype(dt)
     try:
+        M = 32768
+        x, w, b = randn(M, K, dtype=dt), randn(N, K, dtype=dt, seed=1) * 0.1, randn(N, seed=2)
+        res = randn(M, N, seed=3) * 2 + 0.5
+        res[:7] += 40.0  # rows whose mean dwarfs their spread: the single-pass variance must survive it
+        lnm = nn.LayerNorm(N).to(DEV)
+        with torch.no_grad():
+            lnm.weight.copy_(randn(N, seed=4)); lnm.bias.copy_(randn(N, seed=5))
+        ref = res + x.float() @ w.float().t() + b
+        ref_ln = torch.nn.functional.layer_norm(ref, (N,), lnm.weight, lnm.bias, lnm.eps)
+        out = res.clone()
+        assert ops.FUSE_LN
         xn = ops.linear_residual_ln(x, w, b, out, lnm)
+        assert L.lib.rf_gemm_last_family() == 3  # the persistent kernel took it
+        assert xn is not None and xn.dtype == dt
+        tol = 1.0 if dt == torch.bfloat16 else 0.15
+        assert rel_err(out, ref) < 2e-2 * tol
+        assert rel_err(xn, ref_ln) < 3e-2 * tol
+        # against the two-launch form on the same operands: identical fp32 rows, LayerNorm equal to 16-bit rounding
+        out2 = res.clone()
+        ops.linear(x, w, b, out=out2, residual=out2)
+        assert torch.equal(out, out2) or rel_err(out, out2) < 1e-6
+        xn2 = ops.layernorm(out2, lnm.weight.detach(), lnm.bias.detach(), eps=lnm.eps, out_dtype=dt)
+        assert rel_err(xn, xn2) < 1e-2 * tol
+        # twice: bitwise equal
+        out3 = res.clone()
+        xn3 = ops.linear_residual_ln(x, w, b, out3, lnm)
+        assert torch.equal(out3, out) and torch.equal(xn3, xn)
     finally:
-        ops.FUSE_LN_288 = False
-    assert xn is not None and xn.dtype == torch.bfloat16
-    assert rel_err(out, ref) < 2e-2
-    assert rel_err(xn, ref_ln) < 3e-2
-    # against the two-launch form on the same operands: identical fp32 rows, LayerNorm equal to bf16 rounding
-    out2 = res.clone()
-    ops.linear(x, w, b, out=out2, residual=out2)
-    assert rel_err(out, out2) < 1e-6
-    xn2 = ops.layernorm(out2, lnm.weight.detach(), lnm.bias.detach(), eps=lnm.eps, out_dtype=torch.bfloat16)
-    assert rel_err(xn, xn2) < 1e-2
+        R.set_compute_dtype(torch.bfloat16)
 
 
 @pytest.mark.parametrize("cfg", list(range(1, 19)))
@@ -166,11 +177,11 @@ def test_gemm_fused_residual_layernorm(N, K):
     ref = res + x.float() @ w.float().t() + b
     ref_ln = torch.nn.functional.layer_norm(ref, (N,), lnm.weight, lnm.bias, lnm.eps)
     out = res.clone()
-    ops.FUSE_LN = True
+    ops.FUSE_LN_ANY = True
     try:
         xn = ops.linear_residual_ln(x, w, b, out, lnm)
     finally:
-        ops.FUSE_LN = False
+        ops.FUSE_LN_ANY = False
     assert xn is not None and xn.dtype == torch.bfloat16
     assert rel_err(out, ref) < 2e-2
     assert rel_err(xn, ref_ln) < 3e-2

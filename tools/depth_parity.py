@@ -111,13 +111,13 @@ def run(args):
     torch.manual_seed(1234)
     model = R.RoseTTAFold(**cfg).to(dev)
     g = torch.Generator().manual_seed(0)
-    msa = torch.randint(0, 21, (1, args.N, args.L), generator=g)
+    msa = torch.randint(0, 21, (args.B, args.N, args.L), generator=g)
     seq = msa[:, 0].clone()
-    aa = torch.arange(args.L).unsqueeze(0)
+    aa = torch.arange(args.L).unsqueeze(0).repeat(args.B, 1)
     dmsa, dseq, daa = msa.to(dev), seq.to(dev), aa.to(dev)
     M.RT.struct_inputs_fp32 = not args.struct_lowp
     modes = [m for m in args.modes.split(",") if m]
-    res = {"config": {"N": args.N, "L": args.L, "blocks": f"{n2}+{n3}", "n_enc": 4, "struct_inputs_fp32": not args.struct_lowp,
+    res = {"config": {"B": args.B, "N": args.N, "L": args.L, "blocks": f"{n2}+{n3}", "n_enc": 4, "struct_inputs_fp32": not args.struct_lowp,
                       "reference": "CPU oracle (oracle/rf_oracle.py)" if args.oracle else "exact-fp32 mode of the library"}}
     traces = {}
     for name in (["fp32"] if "fp32" not in modes else []) + modes:
@@ -148,6 +148,7 @@ if __name__ == "__main__":
     ap.add_argument("--oracle", action="store_true")
     ap.add_argument("--struct-lowp", action="store_true")
     ap.add_argument("--modes", default="bf16,fp16")
+    ap.add_argument("--B", type=int, default=1)
     ap.add_argument("--N", type=int, default=128)
     ap.add_argument("--L", type=int, default=256)
     ap.add_argument("--n-two", type=int, default=8)
