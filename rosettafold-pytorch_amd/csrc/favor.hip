@@ -80,6 +80,19 @@ __device__ __forceinline__ void fv_load_tile(char* smem, int lds_off, const h16_
 __device__ __forceinline__ unsigned pack2(float a, float b) { return rf_pack2_h16(a, b); }
 __device__ __forceinline__ float rbf(float x) { return h2f(f2h(x)); }
 
+// The value of an MFMA accumulator register that an LDS instruction (the denominator broadcast: __shfl = ds_bpermute_b32) is
+// about to read.  gfx950 does not interlock an LDS / VALU / VMEM read of a v_mfma destination: the 7 wait states (4-pass
+// 16x16x32) are software's job, and hipcc's hazard recognizer does NOT cover the path that reaches the reader through the
+// loop-exit branch behind the accumulator's last MFMA.  Round 2's kernel had exactly that (`v_mfma ... v[26:29]; s_cbranch
+// .LBB5_70; .LBB5_70: ds_bpermute_b32 v9, v54, v26`, zero wait states): whenever the SIMD's other wave kept the matrix pipe
+// busy, the younger wave's shuffle read the denominator before the last feature block had been added, and its 16 output rows
+// came out scaled by 1.01 - 1.08 in a few items per launch (tools/favor_rootcause/: experiments, forensics, ISA).  The nops
+// live in the SAME block as the reader, so every path passes them; tools/isa_hazard_scan.py audits the whole library.
+__device__ __forceinline__ float fv_mfma_done(float acc_reg) {
+  asm volatile("s_nop 7\n\ts_nop 3" : "+v"(acc_reg));
+  return acc_reg;
+}
+
 union Frag {
   h16x8 v;
   unsigned u[4];
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(256, 1) void favor_attention_kernel(const FavorAttn
     // epilogue: out[s][h*64 + d] = num[d][s] / num[64][s]; lane owns 4 consecutive d of row s
 #pragma unroll
     for (int t = 0; t < ST; ++t) {
-      const float dn = __shfl(num[4][t][0], fr, 64);  // row d = 64 lives in register 0 of the fq == 0 lanes
+      const float dn = __shfl(fv_mfma_done(num[4][t][0]), fr, 64);  // row d = 64 lives in register 0 of the fq == 0 lanes
       const float inv = 1.f / dn;
       const int s = qc * LS + (wave * ST + t) * 16 + fr;
       h16_t* orow = p.out + ob + (int64_t)s * p.o_s;
@@ -485,13 +498,11 @@ template <int LS, bool SOFTMAX>
 __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAttnP p) {
   constexpr int NSB = LS / 32;                    // s-blocks (pairs of s-tiles) per chunk
   constexpr int NSBH = NSB / 2;                   // per sequence half
-  // s-tiles per wave in phase B: two from LS = 128 up, so that at LS = 128 only the four older waves (one per SIMD) run
-  // phase B.  With one s-tile on all eight waves (the round-1 split of LS = 128) this kernel was NOT run-to-run
-  // reproducible after the round-2 changes: in a fraction of the items one wave of the younger half (4-7) wrote 16 rows
-  // that were off by a few percent (tools/determinism_favor.py, tools/determinism_favor_where.py; every variant of the
-  // barriers / waits / DMA form left it in; LS = 64 and LS = 256 never showed it).  The cause is not established; this
-  // split was bitwise reproducible in every run tried (72 x 12288 items per box) and costs ~13 % at LS = 128.
-  constexpr int STB = LS >= 128 ? 2 : 1;
+  // s-tiles per wave in phase B: one up to LS = 128 (all eight waves run phase B at LS = 128), two at LS = 256.  Round 2
+  // shipped two from LS = 128 up -- only the four older waves ran phase B there, ~13 % slower -- because the one-tile form was
+  // not run-to-run reproducible.  Round 3 found the cause (an MFMA result read too early by the denominator shuffle, see
+  // fv_mfma_done above) and fixed THAT; the split is the fast one again.
+  constexpr int STB = LS >= 128 ? LS / 128 : 1;
   constexpr int NWB = LS / (16 * STB);            // waves active in phase B (8 at LS = 256, 4 at LS = 128 and 64)
   constexpr int PC_OFF = 0;
   constexpr int K_OFF = FV_MPAD * 128;
@@ -740,8 +751,27 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
           *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq)) = w;
         }
       }
-    fv_lds_barrier();  // every wave is through phase A
+    fv_lds_barrier();  // every wave is through phase A: the K and V tiles are free again
     FV_STAMP(2)
+    // K/V prefetch of the next item, in flight across the combine and phase B.  (Round 2 had moved it behind the combine's
+    // barrier because that made the then unexplained wrong rows rarer: it only shifted the timing of the early MFMA-result
+    // read, see fv_mfma_done.)  Pin the Q fragments first (loaded a whole phase ago): hipcc's own wait for them lands here,
+    // BEFORE the prefetch DMAs are issued; left to itself it waits at their first use in phase B with vmcnt(0), which also
+    // drains the K/V prefetch it cannot count (in-order counter) and serialises the item pipeline.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < STB; ++t) {
+      asm volatile("" : "+v"(qf[t][0]), "+v"(qf[t][1]));
+    }
+    {
+      const int nxt = item + gridDim.x;
+      if (nxt < p.nitems) {
+        int64_t xb2, ob2;
+        item_base(nxt, xb2, ob2);
+        load_tile8(K_OFF, p.qkv + xb2 + p.k_off, p.x_s, LS_TAG);
+        load_tile8(V_OFF, p.qkv + xb2 + p.v_off, p.x_s, LS_TAG);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 5; ++j)
       if (j < nm && mine(j)) {
@@ -758,29 +788,6 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
         }
       }
     fv_lds_barrier();  // ctx^T complete
-    // The K/V prefetch of the next item is issued HERE, after the combine's barrier, not right after the publish barrier
-    // where the tiles are first free: with the DMAs in flight across the combine and its barrier, single waves of the
-    // younger half produced slightly wrong rows in a fraction of the items (run-to-run differences at LS = 128, found by
-    // tools/determinism_favor.py; every fence / full-wait variant of the barriers left it in, moving the issue point
-    // removed it on every box tried).  Cause not established; the later issue point costs no measurable time.
-    // Pin the Q fragments here (loaded a whole phase ago): hipcc's own wait for them lands at this point, BEFORE the
-    // prefetch DMAs are issued; left to itself it waits at their first use in phase B with vmcnt(0), which also drains
-    // the K/V prefetch it cannot count (in-order counter) and serialises the item pipeline.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int t = 0; t < STB; ++t) {
-      asm volatile("" : "+v"(qf[t][0]), "+v"(qf[t][1]));
-    }
-    {
-      const int nxt = item + gridDim.x;
-      if (nxt < p.nitems) {
-        int64_t xb2, ob2;
-        item_base(nxt, xb2, ob2);
-        load_tile8(K_OFF, p.qkv + xb2 + p.k_off, p.x_s, LS_TAG);
-        load_tile8(V_OFF, p.qkv + xb2 + p.v_off, p.x_s, LS_TAG);
-      }
-    }
-
     FV_STAMP(3)
     // ---------------- phase B ----------------
     for (int qc = 0; qc < nch; ++qc) {
@@ -893,7 +900,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
         FV_STAMP(4)
 #pragma unroll
         for (int t = 0; t < STB; ++t) {
-          const float dn = __shfl(num[4][t][0], fr, 64);
+          const float dn = __shfl(fv_mfma_done(num[4][t][0]), fr, 64);
           const float inv = 1.f / dn;
           const int s = qc * LS + (wave * STB + t) * 16 + fr;
           h16_t* orow = p.out + ob + (int64_t)s * p.o_s;
