@@ -20,7 +20,8 @@ at N=1:
   * cpu_baseline: the CPU oracle (oracle/rf_oracle.py, pinned to the reference's golden vectors) on the host cores: one
     layer of each kind at the bench shapes (B=1), warm-up + best of 3, scaled by the layer counts.
 Other workloads: --config 4 (BASELINE.json configs[3]: B=1, N=64, L=1024) and --config 5 (configs[4]: the SE(3) structure
-module alone, B=8, L=256, k=128) print a JSON line of the same form (no roofline / cpu legs).
+module alone, B=8, L=256, k=128) print a JSON line of the same form with their own `roofline` (dominant rf_gemm family of
+that workload, PMC files profiles/r03_config{4,5}_*); no parity / cpu legs.
 """
 import argparse
 import hashlib
@@ -72,7 +73,7 @@ def make_inputs(B, N, L, seed, device):
     return msa.to(device), seq.to(device), aa_idx.to(device)
 
 
-def profile_gemms(model, inputs):
+def profile_gemms(run):
     """One extra forward with HIP events around every rf_gemm launch (same stream the kernels run on)."""
     from rosettafold_pytorch_amd import ops
     recs = []
@@ -95,7 +96,7 @@ def profile_gemms(model, inputs):
 
     ops.lib.rf_gemm = wrapped
     try:
-        model(*inputs)
+        run()
         torch.cuda.synchronize()
     finally:
         ops.lib.rf_gemm = orig
@@ -354,23 +355,24 @@ def main():
                        "parallelism": f"batch-sharded x{world} (replicated weights)"},
         }
         full = args.config == 2 and args.dtype == "bf16"
-        if world == 1 and full and not args.no_roofline:
-            fams, shapes = profile_gemms(model, inputs)
+        pmc_tag = "r03_" if args.config == 2 else f"r03_config{args.config}_"
+        if world == 1 and args.dtype == "bf16" and args.config in (2, 4, 5) and not args.no_roofline:
+            fams, shapes = profile_gemms(run)
             name, (secs, flops, n, nbytes) = max(fams.items(), key=lambda kv: kv[1][0])
             traffic, tnote = None, "no PMC collection for this tree (tools/pmc_traffic.py)"
             try:
-                with open(os.path.join(ROOT, "profiles", "r03_traffic_pmc.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", pmc_tag + "traffic_pmc.json")) as fh:
                     pm = json.load(fh)
                 if pm.get("tree") == tree_hash():
                     traffic = pm["families"][name.split(" ")[0]]["hbm_bytes_per_launch"]
                     tnote = f"rocprofv3 PMC passes (FETCH_SIZE x2, WRITE_SIZE) on this tree ({pm['tree']})"
                 else:
-                    tnote = f"stale: profiles/r03_traffic_pmc.json was collected on tree {pm.get('tree')}, this is {tree_hash()}"
+                    tnote = f"stale: profiles/{pmc_tag}traffic_pmc.json was collected on tree {pm.get('tree')}, this is {tree_hash()}"
             except (OSError, KeyError, ValueError):
                 pass
             mfma_util = None  # matrix-pipe busy fraction from the hardware counters (tools/pmc_mfma.py), same staleness rule
             try:
-                with open(os.path.join(ROOT, "profiles", "r03_mfma_pmc.json")) as fh:
+                with open(os.path.join(ROOT, "profiles", pmc_tag + "mfma_pmc.json")) as fh:
                     pm = json.load(fh)
                 if pm.get("tree") == tree_hash():
                     mfma_util = {k: v["mfma_util"] for k, v in pm["families"].items() if v.get("mfma_util")}

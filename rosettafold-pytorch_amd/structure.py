@@ -251,6 +251,26 @@ class SE3Transformer(nn.Module):
         return h
 
 
+_PENDING_EDGE_COUNTS = []   # (count tensor [min(edges, cap), edges], capacity) of the graphs built since the last check
+
+
+def check_edge_capacity(pending=None):
+    """Raises if a kNN graph had more edges than its static capacity (rf_edges_from_mask drops the overflow and reports the
+    true count in count[1]): the capacity bound k + 2*(kmin-1) per row holds for strictly increasing residue indices,
+    which the public forward()s verify -- this is the backstop behind that argument.  One 8-byte read-back per graph,
+    taken at the END of a public forward (the launches are already queued; no bubble in front of them).
+    `pending`: explicit list (graph.GraphedForward keeps the captured graph's counts); default: everything recorded since
+    the last check, which is cleared."""
+    items = pending if pending is not None else list(_PENDING_EDGE_COUNTS)
+    if pending is None:
+        _PENDING_EDGE_COUNTS.clear()
+    for count, cap in items:
+        kept, total = count.tolist()
+        if total > cap:
+            raise L.RfmiError(f"kNN graph overflow: {total} edges for a capacity of {cap} (residue indices not strictly "
+                              f"increasing?) -- {total - kept} edges were dropped, the result is not the reference's")
+
+
 def build_graph(xyz, edge_emb, aa_idx, n_neighbors, kmin=9, monotonic=True):
     """rf.py:823-862 on the device: dense mask -> compacted edge list (+ dense edge-id map) -> per-edge geometry.
     The edge count stays on the device; every per-edge buffer has a static capacity: B*L*min(L, k+2*(kmin-1)) when
@@ -262,6 +282,8 @@ def build_graph(xyz, edge_emb, aa_idx, n_neighbors, kmin=9, monotonic=True):
     cap = (B * Lr * per_row + 63) // 64 * 64
     mask = ops.knn_mask(xyz, aa_idx, k, kmin)
     src, dst, eid, count = ops.edges_from_mask(mask, cap)
+    _PENDING_EDGE_COUNTS.append((count, cap))
+    del _PENDING_EDGE_COUNTS[:-64]   # callers of the internal run() paths never check: keep the list bounded
     basis, feat = ops.se3_edge_geometry(xyz, edge_emb, src, dst, count, cap)
     return {"src": src, "dst": dst, "eid": eid, "count": count, "basis": basis, "feat": feat, "cap": cap,
             "V": B * Lr, "L": Lr, "mask": mask}
@@ -305,8 +327,10 @@ class CoordUpdateWithMsaAndPair(RFModule):
 
     def forward(self, xyz, msa, pair, aa_idx, seq_onehot):
         mono = check_index_range(None, None, aa_idx.contiguous(), 1, 2 ** 31 - 1)
-        return self.run(xyz.float(), msa.float().contiguous(), pair.float().contiguous(), aa_idx, seq_onehot.float(),
-                        monotonic=mono)
+        out = self.run(xyz.float(), msa.float().contiguous(), pair.float().contiguous(), aa_idx, seq_onehot.float(),
+                       monotonic=mono)
+        check_edge_capacity()
+        return out
 
 
 # ================================================================================================
@@ -415,7 +439,9 @@ class ThreeTrackBlock(TwoTrackBlock):
     def forward(self, msa, pair, xyz, seq_onehot, aa_idx):
         msa = fresh_f32(msa)
         mono = check_index_range(None, None, aa_idx.contiguous(), 1, 2 ** 31 - 1)
-        return self.run3(msa, pair.float().contiguous(), xyz.float(), seq_onehot.float(), aa_idx, mono)
+        out = self.run3(msa, pair.float().contiguous(), xyz.float(), seq_onehot.float(), aa_idx, mono)
+        check_edge_capacity()
+        return out
 
 
 class FinalBlock(TwoTrackBlock):
@@ -437,7 +463,9 @@ class FinalBlock(TwoTrackBlock):
     def forward(self, msa, pair, xyz, seq_onehot, aa_idx):
         msa = fresh_f32(msa)
         mono = check_index_range(None, None, aa_idx.contiguous(), 1, 2 ** 31 - 1)
-        return self.run3(msa, pair.float().contiguous(), xyz.float(), seq_onehot.float(), aa_idx, mono)
+        out = self.run3(msa, pair.float().contiguous(), xyz.float(), seq_onehot.float(), aa_idx, mono)
+        check_edge_capacity()
+        return out
 
 
 class RoseTTAFold(RFModule):
@@ -473,6 +501,16 @@ class RoseTTAFold(RFModule):
             # the reference raises IndexError for out-of-range tokens / residue indices (nn.Embedding, rf.py:73,98)
             mono = check_index_range(msa, seq, aa_idx, self.msa_emb.to_embedding.num_embeddings,
                                      min(self.msa_emb.pos_enc.max_len, self.pair_emb.pos_enc.max_len))
+            _PENDING_EDGE_COUNTS.clear()
+            out = self.forward_validated(msa, seq, aa_idx, mono)
+            check_edge_capacity()
+            return out
+
+    @torch.no_grad()
+    def forward_validated(self, msa, seq, aa_idx, mono=True):
+        """forward() behind the input validation: launches only, no host read of device data, so it can be recorded into
+        a hipGraph (graph.GraphedForward).  `mono` = aa_idx strictly increasing in every sample (what forward() checks)."""
+        with torch.cuda.device(msa.device):
             m = self.msa_emb.run(msa, aa_idx)
             p = self.pair_emb.run(seq, aa_idx)
             onehot = ops.onehot(seq, 21)  # rf.py:1276

@@ -128,6 +128,25 @@ def test_non_monotonic_aa_idx_uses_the_general_capacity():
     assert rel(st, rs) < 5e-4 and rel(xo, rx) < 5e-4
 
 
+def test_graph_overflow_is_reported_not_silent():
+    """ADVICE r2: if the caller's `monotonic` promise is wrong the static capacity k + 2*(kmin-1) per row overflows;
+    rf_edges_from_mask drops the surplus (count[1] = true count) and check_edge_capacity() turns that into an error at
+    the end of the public forward."""
+    Lr, k = 48, 4
+    g = torch.Generator().manual_seed(5)
+    xyz = torch.randn(1, Lr, 3, 3, generator=g).to(DEV)
+    edge = torch.randn(1, Lr, Lr, 8, generator=g).to(DEV)
+    aa = torch.zeros(1, Lr, dtype=torch.long, device=DEV)          # complete graph: 47 edges per row > 4 + 16
+    S._PENDING_EDGE_COUNTS.clear()
+    gr = S.build_graph(xyz, edge, aa, k, monotonic=True)           # the lie
+    with pytest.raises(_lib.RfmiError, match="kNN graph overflow"):
+        S.check_edge_capacity()
+    assert gr["count"].tolist() == [gr["cap"], Lr * (Lr - 1)]
+    assert not S._PENDING_EDGE_COUNTS                               # drained
+    S.build_graph(xyz, edge, aa, k, monotonic=False)
+    S.check_edge_capacity()                                         # the general capacity holds every graph
+
+
 def test_edges_from_mask_never_writes_past_capacity():
     B, Lr, cap = 1, 32, 100
     mask = torch.ones(B, Lr, Lr, device=DEV, dtype=torch.uint8)  # 1024 edges >> capacity
