@@ -167,6 +167,21 @@ int rf_tied_attention(const void* q, const void* k, const void* v, const int64_t
                       void* out, const int64_t o_strides[4], int B, int H, int N, int L, int d_head, float* partial_ws,
                       int64_t partial_ws_elems, void* stream);
 
+/* Feed-forward block with its residual in ONE launch (FeedForward, rf.py:270-281, inside the residual wrappers of the
+ * encoder / axial layers rf.py:284-354, 483-560):
+ *   out[m,:] = residual[m,:] + W2 relu(W1 x[m,:] + b1) + b2          (fp32; out may alias residual: in place)
+ *   ln_out[m,:] = gamma * (out[m,:] - mean) * rstd + beta             (optional 16-bit copy: the NEXT layer's LayerNorm)
+ * The hidden activations never reach HBM.  x: 16-bit [M, D] (ldx elements between rows), D = 288 or 384, hidden % 32 == 0,
+ * M % 128 == 0.  w_packed: both weight matrices in the fragment order the kernel streams (16-bit, 2 * D * hidden elements):
+ * for chunk c of 32 hidden units, first D/32 * 2 pieces of W1, then D/16 pieces of W2, a piece = 64 lanes x 8 elements,
+ * lane = 16 fq + fr:
+ *   W1 piece (ks, ht):  element j of the lane = W1[32 c + 16 ht + fr][32 ks + 8 fq + j]          (W1: [hidden, D])
+ *   W2 piece (nt):      element j of the lane = W2[16 nt + fr][32 c + 16 (j >> 2) + 4 fq + (j & 3)]  (W2: [D, hidden])
+ * (ops.ffn_pack builds it once per module).  b1 [hidden], b2 [D], gamma / beta [D]: fp32. */
+int rf_ffn_fused(const void* x, int64_t ldx, const void* w_packed, const float* b1, const float* b2, const float* residual,
+                 int64_t ldr, float* out, int64_t ldo, void* ln_out, int64_t ldn, const float* ln_gamma,
+                 const float* ln_beta, float ln_eps, int64_t M, int D, int hidden, void* stream);
+
 /* PositionWiseWeightFactor in collapsed form on the matrix pipe (rf.py:205-217):
  *   w[b,h,n,l] = softmax_n( scale * sum_c xn[b,n,l,c] * u[b,l,h,c] ),   u[b,l,h,:] = W_k[h*dh:(h+1)*dh, :]^T to_q(x_0)[b,l,h,:]
  * (to_k's bias is constant in n and cancels in the softmax, so the to_k projection over all N rows is never formed).

@@ -6,7 +6,8 @@ import os
 import torch  # noqa: F401  -- must be loaded first: librfmi.so binds to the HIP runtime torch already brought in
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librfmi.so")
+# RFMI_LIB: tuning hook -- load another build of the bf16 library (e.g. an ablation build, csrc/Makefile ABLATION=1 LIB=...)
+LIB_PATH = os.environ.get("RFMI_LIB") or os.path.join(_HERE, "librfmi.so")
 
 RF_F32, RF_BF16, RF_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_ELU, ACT_RELU_EPS, ACT_LEAKY, ACT_BLOCK_LN32 = 0, 1, 2, 3, 4, 5
@@ -50,6 +51,7 @@ PROTOTYPES = {
     "rf_tied_av": [vp, vp, C.POINTER(I64x4), vp, C.POINTER(I64x4), i32, i32, i32, i32, i32, vp],
     "rf_tied_attention": [vp, vp, vp, C.POINTER(I64x4), C.POINTER(I64x4), vp, C.POINTER(I64x3), f32, vp, vp, i64, vp,
                           C.POINTER(I64x4), i32, i32, i32, i32, i32, vp, i64, vp],
+    "rf_ffn_fused": [vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, f32, i64, i32, i32, vp],
     "rf_outer_product_ln_linear": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, f32, vp, i64, vp],
     "rf_poswise_collapsed": [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp],
     "rf_poswise": [vp, i32, i64, vp, i64, i32, i32, i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp],

@@ -255,6 +255,10 @@ class FeedForward(RFModule):
     def apply_residual(self, xn, x_res, next_ln=None):
         """x_res += W2 relu(W1 xn + b1) + b2   (x_res fp32, in place).  With `next_ln` the second GEMM's epilogue also
         emits next_ln(x_res) (returned, or None when the fused form does not apply)."""
+        if ops.ffn_fused_applies(xn, x_res, self.net[0].in_features, self.net[0].out_features):
+            # one launch, hidden activations on chip (csrc/ffn.hip); the weights are packed once per module
+            wp = self.cached("ffn_packed", lambda: ops.ffn_pack(self.net[0].weight, self.net[3].weight, T()))
+            return ops.ffn_fused(xn, wp, _f(self.net[0].bias), _f(self.net[3].bias), x_res, next_ln)
         w1, b1, w2, b2 = self.wt("w1", self.net[0]), _f(self.net[0].bias), self.wt("w2", self.net[3]), _f(self.net[3].bias)
         d_ff, R = w1.shape[0], xn.numel() // xn.shape[-1]
         pr = row_panels(R, d_ff * xn.element_size(), 256) if x_res.is_contiguous() and xn.is_contiguous() else R

@@ -578,6 +578,49 @@ FUSE_LN = not bool(int(__import__("os").environ.get("RF_NO_FUSED_LN", "0")))
 FUSE_LN_ANY = False
 
 
+def ffn_pack(w1, w2, dtype=None):
+    """Both feed-forward weight matrices (w1 [hidden, D], w2 [D, hidden], nn.Linear layout) in the fragment order
+    rf_ffn_fused streams them (include/rfmi.h): per chunk of 32 hidden units D/16 one-KB pieces of W1, then D/16 of W2."""
+    hid, D = w1.shape
+    if w2.shape != (D, hid) or D % 32 or hid % 32:
+        raise ValueError(f"ffn_pack: w1 {tuple(w1.shape)} / w2 {tuple(w2.shape)}")
+    NC, KS, NT = hid // 32, D // 32, D // 16
+    w1 = w1.detach().float().view(NC, 2, 16, KS, 4, 8).permute(0, 3, 1, 4, 2, 5)      # (c, ks, ht, fq, fr, j)
+    w2 = w2.detach().float().view(NT, 16, NC, 2, 4, 4).permute(2, 0, 4, 1, 3, 5)      # (c, nt, fq, fr, j >> 2, j & 3)
+    packed = torch.cat([w1.reshape(NC, -1), w2.reshape(NC, -1)], 1)
+    return packed.to(dtype if dtype is not None else h16()).contiguous()
+
+
+# One-launch feed-forward (csrc/ffn.hip): correct, but at the forward's shapes it only ties with the two-GEMM path (402 vs 397 us
+# per MSA block, 511-525 vs 485 us per pair block; DESIGN.md section 5 "fused feed-forward") -- the weight stream of a 128-token
+# tile through L2 -> LDS costs what the hidden round trip through HBM costs -- so it is opt-in (RF_FUSED_FFN=1).
+FUSE_FFN = bool(int(__import__("os").environ.get("RF_FUSED_FFN", "0")))
+
+
+def ffn_fused_applies(xn, x_res, D, hidden):
+    rows = x_res.numel() // D
+    return (FUSE_FFN and is_h16(xn.dtype) and D in (288, 384) and hidden % 32 == 0 and rows % 128 == 0 and rows >= 16384
+            and x_res.is_contiguous() and xn.is_contiguous() and x_res.dtype == F32
+            and 288 <= hidden and hidden * 4 <= 160 * 1024 - 153 * 1024)
+
+
+def ffn_fused(xn, w_packed, b1, b2, x_res, next_ln=None):
+    """x_res += W2 relu(W1 xn + b1) + b2 in one launch (csrc/ffn.hip); returns next_ln(x_res) in the 16-bit type when
+    `next_ln` (an nn.LayerNorm) is given, else None."""
+    D = x_res.shape[-1]
+    rows = x_res.numel() // D
+    hidden = b1.numel()
+    _need_cuda(xn, w_packed, x_res)
+    if w_packed.numel() != 2 * D * hidden or w_packed.dtype != xn.dtype:
+        raise ValueError("ffn_fused: packed weights do not match (ops.ffn_pack)")
+    out_ln = torch.empty(x_res.shape, device=x_res.device, dtype=xn.dtype) if next_ln is not None else None
+    g = next_ln.weight.detach() if next_ln is not None else None
+    b = next_ln.bias.detach() if next_ln is not None else None
+    check(lib.rf_ffn_fused(ptr(xn), D, ptr(w_packed), ptr(b1), ptr(b2), ptr(x_res), D, ptr(x_res), D, ptr(out_ln), D, ptr(g), ptr(b),
+                           float(next_ln.eps) if next_ln is not None else 0.0, rows, D, hidden, stream()), "rf_ffn_fused")
+    return out_ln
+
+
 def linear_residual_ln(x, w, bias, x_res, next_ln):
     """x_res += x @ w^T + bias (fp32, in place).  If `next_ln` (an nn.LayerNorm) is given and the fused epilogue applies
     (bf16 operands, full rows per tile), also returns LayerNorm_next(x_res) in bf16; otherwise returns None and the

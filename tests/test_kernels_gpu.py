@@ -156,6 +156,52 @@ def test_gemm_persistent_fused_layernorm(N, K, dt):
         R.set_compute_dtype(torch.bfloat16)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("D,with_ln", [(384, True), (384, False), (288, True), (288, False)])
+def test_ffn_fused(D, with_ln, dt):
+    """rf_ffn_fused (csrc/ffn.hip, opt-in RF_FUSED_FFN=1): x_res += W2 relu(W1 xn + b1) + b2 [+ the next LayerNorm] in one
+    launch, hidden activations on chip, against an fp32 formula with the same 16-bit rounding of the hidden activations and
+    against the two-GEMM path; several tiles per workgroup (M = 128 * 3 * CUs would be slow: 40960 rows = 320 tiles)."""
+    import torch.nn as nn
+    import rosettafold_pytorch_amd as R
+    R.set_compute_dtype(dt)
+    old = ops.FUSE_FFN
+    try:
+        torch.manual_seed(D + with_ln)
+        M = 40960
+        ff = R.FeedForward(D, 4 * D, 0.0).to(DEV)
+        lnm = nn.LayerNorm(D).to(DEV)
+        with torch.no_grad():
+            lnm.weight.copy_(randn(D, seed=4)); lnm.bias.copy_(randn(D, seed=5))
+        xn, x0 = randn(M, D, dtype=dt), randn(M, D, seed=3) * 2 + 0.5
+        x0[:7] += 40.0
+
+        def run(fused):
+            ops.FUSE_FFN = fused
+            x = x0.clone()
+            return x, ff.apply_residual(xn, x, lnm if with_ln else None)
+        xa, la = run(True)
+        assert ops.ffn_fused_applies(xn, x0, D, 4 * D)
+        xb, lb = run(False)
+        w1, w2 = ff.net[0].weight.to(dt).float(), ff.net[3].weight.to(dt).float()
+        hid = torch.relu(xn.float() @ w1.t() + ff.net[0].bias).to(dt).float()
+        ref = x0 + hid @ w2.t() + ff.net[3].bias
+        tol = 1.0 if dt == torch.bfloat16 else 0.15
+        assert rel_err(xa, ref) < 1e-3 * tol + 2e-5          # fp32 accumulation of 16-bit products: summation order only
+        assert rel_err(xa, xb) < 2e-5
+        if with_ln:
+            ref_ln = torch.nn.functional.layer_norm(ref, (D,), lnm.weight, lnm.bias, lnm.eps)
+            assert la is not None and la.dtype == dt and rel_err(la, ref_ln) < 3e-2 * tol
+            assert rel_err(la, lb) < 1e-2 * tol
+        else:
+            assert la is None
+        xc, lc = run(True)                                     # twice: bitwise equal
+        assert torch.equal(xa, xc) and (la is None or torch.equal(la, lc))
+    finally:
+        ops.FUSE_FFN = old
+        R.set_compute_dtype(torch.bfloat16)
+
+
 @pytest.mark.parametrize("cfg", list(range(1, 19)))
 def test_gemm_all_tile_configs(cfg):
     M, N, K = 777, 600, 352
