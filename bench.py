@@ -159,27 +159,36 @@ def _agreement(lb, xb, pb, lg, xyz, pl):
             "rel_l2": {**{k: rel_l2(lb[k], lg[k]) for k in lg}, "xyz": rel_l2(xb, xyz), "plddt": rel_l2(pb, pl)}}
 
 
-def _time_mode(model, inputs, R, dtype, steps):
+def _time_mode(model, inputs, R, dtype, steps, graph=False):
+    """One compute mode timed like the headline number: eager launches, or (graph=True) replays of one hipGraph."""
     R.set_compute_dtype(dtype)
     try:
         out = model(*inputs)  # warm-up (weight copies of this mode)
         torch.cuda.synchronize()
+        run = lambda: model(*inputs)  # noqa: E731
+        if graph:
+            try:
+                g = R.GraphedForward(model, *inputs)
+                run = lambda: g(*inputs)  # noqa: E731
+            except Exception as e:  # noqa: BLE001
+                log(f"hipGraph capture failed in {dtype} mode ({type(e).__name__}: {e}); eager launches")
         t0 = time.perf_counter()
         for _ in range(steps):
-            out = model(*inputs)
+            out = run()
         torch.cuda.synchronize()
-        return out, 1e3 * (time.perf_counter() - t0) / steps
+        ms = 1e3 * (time.perf_counter() - t0) / steps
+        return (dict(out[0]), out[1].clone(), out[2].clone()), ms
     finally:
         R.set_compute_dtype(torch.bfloat16)
 
 
-def parity_block(model, inputs, out_bf16, R, ms_bf16, steps=2):
+def parity_block(model, inputs, out_bf16, R, ms_bf16, steps=2, graph=False):
     """Every compute mode of the library on the SAME inputs and weights, against the exact-fp32 mode (the mode that
     tests/test_depth_gpu.py and tests/test_config2_gpu.py pin to the CPU oracle at 5e-4 / 2e-5): the timed bf16 path, and
     the fp16-operand build of the same kernels (librfmi_f16.so: same MFMA rate and bytes, 8x smaller operand rounding),
     each with its own step time.  Top-level fields describe the timed (bf16) path."""
     (lg, xyz, pl), ms32 = _time_mode(model, inputs, R, torch.float32, steps)
-    (l16, x16, p16), ms16 = _time_mode(model, inputs, R, torch.float16, max(steps, 3))
+    (l16, x16, p16), ms16 = _time_mode(model, inputs, R, torch.float16, max(steps, 3), graph)
     lb, xb, pb = out_bf16
     bf = _agreement(lb, xb, pb, lg, xyz, pl)
     fp = _agreement(l16, x16, p16, lg, xyz, pl)
@@ -276,6 +285,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on a 1-GPU box)")
+    ap.add_argument("--no-graph", action="store_true", help="issue the forward's launches eagerly instead of replaying one hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -294,6 +304,7 @@ def main():
     R.set_compute_dtype({"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype])
     torch.manual_seed(1234)  # identical weights on every rank
     B, N, L = cfg["B"], cfg["N"], cfg["L"]
+    used_graph = False
     if args.config == 5:
         mc = cfg["model"]
         model = R.CoordUpdateWithMsaAndPair(mc["d_msa"], mc["d_pair"], mc["d_node"], mc["d_edge"], mc["d_state"],
@@ -304,6 +315,16 @@ def main():
         model = R.RoseTTAFold(p_dropout=0.0, **cfg["model"]).to(dev)
         inputs = make_inputs(B, N, L, seed=rank, device=dev)  # independent MSAs per rank
         run = lambda: model(*inputs)  # noqa: E731
+        eager = run
+        if not args.no_graph:
+            # the whole forward as ONE hipGraph (rosettafold-pytorch_amd/graph.py): every step still validates its inputs and
+            # copies them into the graph's static tensors before the replay.  Falls back to eager launches if capture fails.
+            try:
+                graphed = R.GraphedForward(model, *inputs)
+                run = lambda: graphed(*inputs)  # noqa: E731
+                used_graph = True
+            except Exception as e:  # noqa: BLE001
+                log(f"hipGraph capture failed ({type(e).__name__}: {e}); eager launches")
 
     def step():
         out = run()
@@ -352,12 +373,14 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "global_batch": world * B,
-                       "parallelism": f"batch-sharded x{world} (replicated weights)"},
+                       "parallelism": f"batch-sharded x{world} (replicated weights)",
+                       "launch": "one hipGraph replay per step (validation + input copy outside the graph)" if used_graph
+                       else "eager launches through the C ABI"},
         }
         full = args.config == 2 and args.dtype == "bf16"
         pmc_tag = "r03_" if args.config == 2 else f"r03_config{args.config}_"
         if world == 1 and args.dtype == "bf16" and args.config in (2, 4, 5) and not args.no_roofline:
-            fams, shapes = profile_gemms(run)
+            fams, shapes = profile_gemms(eager if args.config != 5 else run)
             name, (secs, flops, n, nbytes) = max(fams.items(), key=lambda kv: kv[1][0])
             traffic, tnote = None, "no PMC collection for this tree (tools/pmc_traffic.py)"
             try:
@@ -395,7 +418,7 @@ def main():
                                                 "algorithmic_GBps": v[3] / max(v[0], 1e-12) / 1e9}
                                             for k, v in fams.items()}}
         if world == 1 and full and not args.no_parity:
-            res["parity"] = parity_block(model, inputs, out, R, 1e3 * dt / args.steps)
+            res["parity"] = parity_block(model, inputs, out, R, 1e3 * dt / args.steps, graph=used_graph)
         if world == 1 and full and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)

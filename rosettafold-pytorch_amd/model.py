@@ -629,10 +629,16 @@ class PerformerSelfAttention(RFModule):
                 # q|k|v written head-major [B, Lo, 3, H, Ls, 64] straight from the projection GEMM's epilogue: every
                 # (b, o, head) tile the FAVOR kernel DMAs is then one contiguous 8 KB x (Ls/64) block
                 qkv = torch.empty(B, Lo, 3, H, Ls, dh, device=dev, dtype=T())
-                so_c, ss_c = 3 * H * Ls * dh, dh
-                c_ro, c_ri = (ss_c, so_c) if axis == 1 else (so_c, ss_c)  # row m = p1*L2 + p2
-                ops.gemm(xn, wqkv, qkv, RB, W3, D, batch=(B, 1, 1), a_bs=(RB * D, 0, 0),
-                         c_bs=(Lo * so_c, 0, 0), c_row=(L2, c_ro, c_ri), c_col=(dh, Ls * dh))
+                so_c = 3 * H * Ls * dh
+                if axis == 2:
+                    # row m = (b, p1, p2) with the sequence along p2: offset (m / L2) * so_c + (m % L2) * dh -- one launch, the
+                    # register-resident-weight GEMM's split-C epilogue (csrc/gemm_wreg.hip)
+                    ops.gemm(xn, wqkv, qkv, R, W3, D, c_row=(L2, so_c, dh), c_col=(dh, Ls * dh))
+                else:
+                    # sequence along p1: offset b * Lo * so_c + p2 * so_c + p1 * dh is a three-level split: one launch per
+                    # batch element (row m = p1 * L2 + p2 inside it: (m / L2) * dh + (m % L2) * so_c)
+                    for b in range(B):
+                        ops.gemm(xn[b], wqkv, qkv[b], RB, W3, D, c_row=(L2, dh, so_c), c_col=(dh, Ls * dh))
                 ops.favor_attention(qkv, pcf, o, (Lo * so_c, so_c, dh, Ls * dh), (RB * inner, so * inner, ss * inner),
                                     0, H * Ls * dh, 2 * H * Ls * dh, B, Lo, H, Ls, dh, m, not gen, eps)
             else:
