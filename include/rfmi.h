@@ -153,6 +153,15 @@ int rf_tied_logits_softmax(const void* q, const void* k, int64_t b_stride, int64
 int rf_tied_av(const void* att, const void* v, const int64_t v_strides[4], void* out, const int64_t o_strides[4], int B,
                int H, int N, int L, int d_head, void* stream);
 
+/* Logits + softmax of the tied attention on head-major operands (rf.py:252-255), the first half of rf_tied_attention:
+ *   att[b,h,i,:] = softmax_j( sum_{n,d} (w[b,h,n,i] * qscale) q[b,n,h,i,d] k[b,n,h,j,d] )      (+ att_sym as in rf_tied_softmax)
+ * Same arguments as rf_tied_attention.  L in {64,128,192,256}, or L in {512,768,1024} (BASELINE.json configs[3]): long rows run
+ * contraction-split over 128-query x 256-key tiles, need partial_ws (>= nsplit * B*H*L*L floats, nsplit = 1 for N <= 64,
+ * doubling until N / nsplit <= 64) and take w == NULL (position weights folded into q by the projection: rf_gemm_desc.rs). */
+int rf_tied_logits(const void* q, const void* k, const int64_t qk_strides[4], const float* w, const int64_t w_strides[3],
+                   float qscale, void* att, float* att_sym, int64_t sym_ld, int B, int H, int N, int L, int d_head,
+                   float* partial_ws, int64_t partial_ws_elems, void* stream);
+
 /* Tied MSA-row attention core in one call (rf.py:252-265): logits + softmax, optional symmetrised map, attention . V.
  *   att[b,h,i,:] = softmax_j( sum_{n,d} (w[b,h,n,i] * qscale) q[b,n,h,i,d] k[b,n,h,j,d] ),  out = att . v
  * q / k share qk_strides {b,n,h,l}; w (fp32, may be NULL = q already scaled) has strides {b,h,n} with l contiguous: the

@@ -49,6 +49,7 @@ PROTOTYPES = {
     "rf_tied_softmax": [vp, vp, i32, vp, i64, i32, i32, i32, vp],
     "rf_tied_logits_softmax": [vp, vp, i64, i64, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp],
     "rf_tied_av": [vp, vp, C.POINTER(I64x4), vp, C.POINTER(I64x4), i32, i32, i32, i32, i32, vp],
+    "rf_tied_logits": [vp, vp, C.POINTER(I64x4), vp, C.POINTER(I64x3), f32, vp, vp, i64, i32, i32, i32, i32, i32, vp, i64, vp],
     "rf_tied_attention": [vp, vp, vp, C.POINTER(I64x4), C.POINTER(I64x4), vp, C.POINTER(I64x3), f32, vp, vp, i64, vp,
                           C.POINTER(I64x4), i32, i32, i32, i32, i32, vp, i64, vp],
     "rf_ffn_fused": [vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, f32, i64, i32, i32, vp],

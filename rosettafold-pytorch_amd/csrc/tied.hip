@@ -198,18 +198,20 @@ struct TiedSplitP {
   const float* w;
   int64_t w_b, w_h, w_n;
   float qscale;
-  float* part;          // fp32 [nsplit][B][H][256][256]
+  float* part;          // fp32 [nsplit][B][H][L][L]
   int64_t split_stride; // elements between the partial tensors of consecutive splits
   int B, H, N, nsplit, nper;  // nper = MSA rows per split (N = nsplit * nper)
+  int L, nrb, nkb;            // L = 128 nrb = 256 nkb: query blocks of 128 rows x key blocks of 256 columns
   int dbg;                    // RF_TIED_DBG (results WRONG when set): 2 fragments read once, 4 no MFMA, 8 no partial stores
 };
 
 template <bool SCALE>
 __global__ __launch_bounds__(512) void tied_logits_split_kernel(const TiedSplitP p) {
-  constexpr int L = 256, RB = 128, NSTG = TIED_SPLIT_NSTG;
-  constexpr int Q_BYTES = RB * 64, K_BYTES = L * 64, STAGE = Q_BYTES + K_BYTES;
-  constexpr int QI = RB / 16, PW = 3;        // (QI + L / 16) DMA pieces of 1 KB per stage = 3 per wave, no padding
-  static_assert(QI + L / 16 == 8 * PW, "pieces per stage");
+  constexpr int KB = 256, RB = 128, NSTG = TIED_SPLIT_NSTG;  // a workgroup: 128 query rows x 256 keys (any L = 256 nkb)
+  constexpr int Q_BYTES = RB * 64, K_BYTES = KB * 64, STAGE = Q_BYTES + K_BYTES;
+  constexpr int QI = RB / 16, PW = 3;        // (QI + KB / 16) DMA pieces of 1 KB per stage = 3 per wave, no padding
+  static_assert(QI + KB / 16 == 8 * PW, "pieces per stage");
+  const int L = p.L;
   constexpr int DUMP = NSTG * STAGE;
   constexpr int W_OFF = DUMP + 1024;         // [nper][128] fp32 position weights of this workgroup's query rows
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -218,18 +220,19 @@ __global__ __launch_bounds__(512) void tied_logits_split_kernel(const TiedSplitP
   const int wr = wave >> 2, wc = wave & 3;   // 64-query half, 64-key quarter
   const int fr = lane & 15, fq = lane >> 4;
 
-  // XCD-aware order: the 2 * nsplit workgroups of one (b, h) run on the same XCD (they share q / k slabs through its L2)
+  // XCD-aware order: the nrb * nkb * nsplit workgroups of one (b, h) run on the same XCD (they share q / k slabs through its L2)
   int lid;
   {
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
     lid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
   }
-  const int rb = lid & 1, sp = (lid >> 1) % p.nsplit;
-  const int bh = lid / (2 * p.nsplit), h = bh % p.H, b = bh / p.H;
+  const int tiles = p.nrb * p.nkb;
+  const int rb = lid % p.nrb, kbk = (lid / p.nrb) % p.nkb, sp = (lid / tiles) % p.nsplit;
+  const int bh = lid / (tiles * p.nsplit), h = bh % p.H, b = bh / p.H;
   const int n0 = sp * p.nper;
   const h16_t* qb = p.q + (int64_t)b * p.b_stride + (int64_t)h * p.h_stride + (int64_t)(rb * RB) * p.l_stride;
-  const h16_t* kb = p.k + (int64_t)b * p.b_stride + (int64_t)h * p.h_stride;
+  const h16_t* kb = p.k + (int64_t)b * p.b_stride + (int64_t)h * p.h_stride + (int64_t)(kbk * KB) * p.l_stride;
 
   const int lrow = lane >> 2;
   const int c_log = (lane & 3) ^ ((0x78 >> (((lrow >> 2) & 3) * 2)) & 3);
@@ -302,35 +305,48 @@ __global__ __launch_bounds__(512) void tied_logits_split_kernel(const TiedSplitP
   }
   if (RF_DBG(p.dbg) & 8) return;
   // partial logits: 16-byte pieces, the four lanes of a row group cover 64 contiguous bytes, a wave's four key tiles 256
-  float* pr = p.part + (int64_t)sp * p.split_stride + (((int64_t)b * p.H + h) * L + rb * RB + wr * 64 + fr) * L + wc * 64 + 4 * fq;
+  float* pr = p.part + (int64_t)sp * p.split_stride + (((int64_t)b * p.H + h) * L + rb * RB + wr * 64 + fr) * L + kbk * KB + wc * 64 + 4 * fq;
 #pragma unroll
   for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) *(f32x4*)(pr + (int64_t)(qt * 16) * L + kt * 16) = acc[kt][qt];
 }
 
-// att[row, :] = softmax(sum_s part[s][row, :]) for L = 256: one wave per row, 4 columns per lane
+// att[row, :] = softmax(sum_s part[s][row, :]) for L = 256 NC: one wave per row, 4 NC columns per lane
+template <int NC>
 __global__ __launch_bounds__(256) void tied_split_softmax_kernel(const float* part, int64_t split_stride, int nsplit,
                                                                  h16_t* att, int64_t rows) {
+  constexpr int L = 256 * NC;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  f32x4 v = *(const f32x4*)(part + row * 256 + lane * 4);
-  for (int s_ = 1; s_ < nsplit; ++s_) v += *(const f32x4*)(part + (int64_t)s_ * split_stride + row * 256 + lane * 4);
-  float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+  f32x4 v[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) v[c] = *(const f32x4*)(part + row * L + c * 256 + lane * 4);
+  for (int s_ = 1; s_ < nsplit; ++s_)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] += *(const f32x4*)(part + (int64_t)s_ * split_stride + row * L + c * 256 + lane * 4);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) mx = fmaxf(mx, fmaxf(fmaxf(v[c][0], v[c][1]), fmaxf(v[c][2], v[c][3])));
   mx = wave_max(mx);
   float sm = 0.f;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    v[e] = __expf(v[e] - mx);
-    sm += v[e];
-  }
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[c][e] = __expf(v[c][e] - mx);
+      sm += v[c][e];
+    }
   sm = wave_sum(sm);
   const float inv = 1.f / sm;
-  uint2 o;
-  o.x = tpack2(v[0] * inv, v[1] * inv);
-  o.y = tpack2(v[2] * inv, v[3] * inv);
-  *(uint2*)(att + row * 256 + lane * 4) = o;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    uint2 o;
+    o.x = tpack2(v[c][0] * inv, v[c][1] * inv);
+    o.y = tpack2(v[c][2] * inv, v[c][3] * inv);
+    *(uint2*)(att + row * L + c * 256 + lane * 4) = o;
+  }
 }
 
 __global__ __launch_bounds__(256) void tied_att_sym_kernel(const h16_t* att, float* sym, int64_t sym_ld, int B, int H, int L) {
@@ -363,11 +379,13 @@ static int launch_tied(const TiedP& p, hipStream_t s) {
   return rf_launch_status();
 }
 
-// contraction-split path: L == 256, N splits into nsplit ranges of <= 64 rows, workspace of nsplit * B*H*L*L floats
+// contraction-split path: L = 256 .. 1024 in steps of 256, N splits into nsplit ranges of <= 64 rows, workspace of
+// nsplit * B*H*L*L floats
 static int tied_logits_split(const TiedP& p0, int L, float* ws, int64_t ws_elems, hipStream_t s) {
   static const bool off = rf_env_flag("RF_NO_TIED_SPLIT");
-  if (off || !ws || L != 256 || p0.N % 2) return 1;  // 1 = not applicable: the caller falls back to the one-pass kernel
-  int nsplit = 2;
+  if (off || !ws || L % 256 || L > 1024 || p0.N % 2) return 1;  // 1 = not applicable: the caller falls back to the one-pass kernel
+  const int nrb = L / 128, nkb = L / 256;
+  int nsplit = L == 256 ? 2 : 1;  // (at L = 256 two splits keep >= 192 workgroups in flight; longer rows have enough tiles)
   while (p0.N / nsplit > 64 && p0.N % (nsplit * 2) == 0) nsplit *= 2;
   const int nper = p0.N / nsplit;
   const int64_t one = (int64_t)p0.B * p0.H * L * L;
@@ -378,9 +396,12 @@ static int tied_logits_split(const TiedP& p0, int L, float* ws, int64_t ws_elems
   p.w = p0.w; p.w_b = p0.w_b; p.w_h = p0.w_h; p.w_n = p0.w_n; p.qscale = p0.qscale;
   p.part = ws; p.split_stride = one;
   p.B = p0.B; p.H = p0.H; p.N = p0.N; p.nsplit = nsplit; p.nper = nper;
+  p.L = L; p.nrb = nrb; p.nkb = nkb;
   p.dbg = p0.dbg;
   const size_t lds = (size_t)TIED_SPLIT_NSTG * (128 * 64 + 256 * 64) + 1024 + (p.w ? (size_t)nper * 512 : 0);
-  const unsigned grid = (unsigned)(p.B * p.H * 2 * nsplit);
+  const int64_t grid64 = (int64_t)p.B * p.H * nrb * nkb * nsplit;
+  if (grid64 > 0x7fffffffLL) return RF_EINVAL;
+  const unsigned grid = (unsigned)grid64;
   if (p.w) {
     if (const int e = rf_enable_big_lds<tied_logits_split_kernel<true>>()) return e;
     hipLaunchKernelGGL(tied_logits_split_kernel<true>, dim3(grid), dim3(512), lds, s, p);
@@ -389,7 +410,13 @@ static int tied_logits_split(const TiedP& p0, int L, float* ws, int64_t ws_elems
     hipLaunchKernelGGL(tied_logits_split_kernel<false>, dim3(grid), dim3(512), lds, s, p);
   }
   const int64_t rows = (int64_t)p.B * p.H * L;
-  hipLaunchKernelGGL(tied_split_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, ws, one, nsplit, p0.att, rows);
+  const dim3 sg((unsigned)((rows + 3) / 4));
+  switch (nkb) {
+    case 1: hipLaunchKernelGGL(tied_split_softmax_kernel<1>, sg, dim3(256), 0, s, ws, one, nsplit, p0.att, rows); break;
+    case 2: hipLaunchKernelGGL(tied_split_softmax_kernel<2>, sg, dim3(256), 0, s, ws, one, nsplit, p0.att, rows); break;
+    case 3: hipLaunchKernelGGL(tied_split_softmax_kernel<3>, sg, dim3(256), 0, s, ws, one, nsplit, p0.att, rows); break;
+    default: hipLaunchKernelGGL(tied_split_softmax_kernel<4>, sg, dim3(256), 0, s, ws, one, nsplit, p0.att, rows); break;
+  }
   return rf_launch_status();
 }
 
@@ -613,19 +640,21 @@ extern "C" int rf_tied_av(const void* att, const void* v, const int64_t v_stride
   return launch_tied_av<64>(p, s);
 }
 
-// Tied attention core in one call: logits + softmax (with the position weights folded in when w != NULL), optional
-// symmetrised map, attention . V.  q / k / v / out strides: {b, n, h, l} in elements, the 32-wide head slice contiguous.
-extern "C" int rf_tied_attention(const void* q, const void* k, const void* v, const int64_t qk_strides[4],
-                                 const int64_t v_strides[4], const float* w, const int64_t w_strides[3], float qscale,
-                                 void* att, float* att_sym, int64_t sym_ld, void* out, const int64_t o_strides[4], int B,
-                                 int H, int N, int L, int d_head, float* partial_ws, int64_t partial_ws_elems, void* stream) {
-  if (!q || !k || !v || !att || !out || B <= 0 || H <= 0 || N <= 0) return RF_EINVAL;
-  if (d_head != 32 || (L != 64 && L != 128 && L != 192 && L != 256)) return RF_EINVAL;
+// Logits + softmax of the tied attention on head-major operands (with the position weights folded in when w != NULL), optional
+// symmetrised map.  L in {64, 128, 192, 256} (one-pass kernel, or the contraction-split form at 256 when a workspace is given)
+// or L in {512, 768, 1024} (contraction-split form over 128-query x 256-key tiles: needs the workspace).
+extern "C" int rf_tied_logits(const void* q, const void* k, const int64_t qk_strides[4], const float* w,
+                              const int64_t w_strides[3], float qscale, void* att, float* att_sym, int64_t sym_ld, int B, int H,
+                              int N, int L, int d_head, float* partial_ws, int64_t partial_ws_elems, void* stream) {
+  if (!q || !k || !att || B <= 0 || H <= 0 || N <= 0) return RF_EINVAL;
+  const bool small = L == 64 || L == 128 || L == 192 || L == 256;
+  if (d_head != 32 || !(small || (L % 256 == 0 && L <= 1024))) return RF_EINVAL;
   if (((uintptr_t)q % 16) || ((uintptr_t)k % 16) || ((uintptr_t)att % 16)) return RF_EALIGN;
   for (int i = 0; i < 4; ++i)
     if (qk_strides[i] % 8) return RF_EALIGN;
   if (w && (((uintptr_t)w % 16) || w_strides[0] % 4 || w_strides[1] % 4 || w_strides[2] % 4)) return RF_EALIGN;
   if (w && N % 4) return RF_EINVAL;  // the weight tile is staged four MSA rows per DMA instruction
+  if (w && !small) return RF_EINVAL; // long rows: fold the weights into q (rf_gemm_desc.rs)
   TiedP p;
   p.q = (const h16_t*)q; p.k = (const h16_t*)k;
   p.b_stride = qk_strides[0]; p.n_stride = qk_strides[1]; p.h_stride = qk_strides[2]; p.l_stride = qk_strides[3];
@@ -637,9 +666,23 @@ extern "C" int rf_tied_attention(const void* q, const void* k, const void* v, co
   if (p.dbg < 0) return p.dbg;
   hipStream_t s = (hipStream_t)stream;
   int rc = tied_logits_split(p, L, partial_ws, partial_ws_elems, s);
-  if (rc == 1) rc = tied_logits_dispatch(p, L, s);
+  if (rc == 1) rc = small ? tied_logits_dispatch(p, L, s) : RF_EINVAL;  // (long rows have no one-pass kernel: the workspace is required)
   if (rc != 0) return rc;
   if (att_sym && (rc = tied_sym(att, att_sym, sym_ld, B, H, L, s)) != 0) return rc;
+  return 0;
+}
+
+// Tied attention core in one call: rf_tied_logits, then attention . V.  q / k / v / out strides: {b, n, h, l} in elements, the
+// 32-wide head slice contiguous.  L in {64, 128, 192, 256} (attention . V keeps whole probability rows in registers).
+extern "C" int rf_tied_attention(const void* q, const void* k, const void* v, const int64_t qk_strides[4],
+                                 const int64_t v_strides[4], const float* w, const int64_t w_strides[3], float qscale,
+                                 void* att, float* att_sym, int64_t sym_ld, void* out, const int64_t o_strides[4], int B,
+                                 int H, int N, int L, int d_head, float* partial_ws, int64_t partial_ws_elems, void* stream) {
+  if (!v || !out) return RF_EINVAL;
+  if (L != 64 && L != 128 && L != 192 && L != 256) return RF_EINVAL;
+  const int rc = rf_tied_logits(q, k, qk_strides, w, w_strides, qscale, att, att_sym, sym_ld, B, H, N, L, d_head, partial_ws,
+                                partial_ws_elems, stream);
+  if (rc != 0) return rc;
   return rf_tied_av(att, v, v_strides, out, o_strides, B, H, N, L, d_head, stream);
 }
 

@@ -478,6 +478,10 @@ class SoftTiedAttentionOverResidues(RFModule):
                 and N % 16 == 0 and N // 16 in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16) and (B * N * Lr) % 256 == 0 and B * N * Lr >= 16384
                 and (6 if Lr >= 256 else 8) * (4096 + Lr * 64) + 1024 + N * 256 <= 160 * 1024):
             return self.attend_head_major(xn, x_res, want_att, next_ln)
+        if (RT.fused_tied and RT.tied_v2 and RT.tied_fold_w and ops.is_h16(T()) and dh == 32 and Lr in (512, 768, 1024) and H <= 16
+                and D in (288, 384) and N % 16 == 0 and N // 16 in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16) and (B * N * Lr) % 256 == 0
+                and B * N * Lr >= 16384):
+            return self.attend_long_rows(xn, x_res, want_att, next_ln)
         # one GEMM for q | k | poswise-k  (N = 3D)
         wcat = self.wcat("qkp", [self.to_q, self.to_k, pw.to_k[0]])
         bcat = self.bcat("qkp", [self.to_q, self.to_k, pw.to_k[0]])
@@ -542,6 +546,43 @@ class SoftTiedAttentionOverResidues(RFModule):
         out = torch.empty(B, N, Lr, D, device=dev, dtype=T())
         ops.tied_attention(qkv[:, :, 0:H], qkv[:, :, H:2 * H], qkv[:, :, 2 * H:], out.view(B, N, Lr, H, dh).permute(0, 1, 3, 2, 4),
                            att, w=None if fold else w, qscale=1.0 if fold else self.scale, att_sym=att_sym)
+        xn_next = ops.linear_residual_ln(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln)
+        return att_sym, xn_next
+
+    def attend_long_rows(self, xn, x_res, want_att, next_ln=None):
+        """L in {512, 768, 1024} (BASELINE.json configs[3]).  Same front as attend_head_major -- collapsed position weights, one
+        projection GEMM writing q|k head-major with w * d_head^-0.5 folded into q on the fp32 accumulators -- then the
+        contraction-split logits kernel over 128-query x 256-key tiles (csrc/tied.hip: rf_tied_logits).  attention . V at
+        these lengths is a plain large GEMM per (b, head) (M = L queries, K = L keys, N = n_seq * 32): it goes to rf_gemm with
+        v written key-contiguous by its projection (keeping whole probability rows in registers, as the L <= 256 kernel
+        does, would need 128 VGPRs per 16 query rows)."""
+        B, N, Lr, D = xn.shape
+        H, dh = self.n_heads, self.d_head
+        dev = xn.device
+        pw = self.poswise_weight
+        q0 = pw.query_proj(xn)
+        wkt = pw.cached("wkT", lambda: pw.to_k[0].weight.detach().t().contiguous().to(T()))
+        u = torch.empty(B, Lr, H, D, device=dev, dtype=T())
+        ops.gemm(q0, wkt, u, B * Lr, D, dh, batch=(H, 1, 1), a_bs=(dh, 0, 0), a_row=(0, 0, D), b_bs=(dh, 0, 0),
+                 b_row=(0, 0, D), c_bs=(D, 0, 0), c_row=(0, 0, H * D))
+        w = ops.poswise_collapsed(xn, u, pw.scale)  # fp32 [B,H,N,L]
+        G = 2 * H
+        lins = [self.to_q, self.to_k]
+        qk = torch.empty(B, N, G, Lr, dh, device=dev, dtype=T())
+        ops.gemm(xn, self.wcat("qk", lins), qk, B * N * Lr, 2 * D, D, bias=self.bcat("qk", lins),
+                 c_row=(Lr, G * Lr * dh, dh), c_col=(dh, Lr * dh), rs=(w, H * N * Lr, N * Lr, dh, D, self.scale))
+        att = torch.empty(B, H, Lr, Lr, device=dev, dtype=T())
+        att_sym = torch.empty(B, Lr, Lr, H, device=dev, dtype=F32) if want_att else None
+        ops.tied_logits(qk[:, :, 0:H], qk[:, :, H:], att, att_sym)
+        # v transposed: v_t[b,n,(h,d),l];  out[b,n,i,(h,d)] = sum_j att[b,h,i,j] v[b,n,h,j,d]   (rf.py:257-258)
+        v_t = torch.empty(B, N, D, Lr, device=dev, dtype=T())
+        ops.gemm(self.wt("v", self.to_v), xn, v_t, D, Lr, D, batch=(B * N, 1, 1), b_bs=(Lr * D, 0, 0),
+                 c_bs=(D * Lr, 0, 0), c_row=(0, 0, Lr), bias=_f(self.to_v.bias), bias_mode=L.BIAS_ROW)
+        out = torch.empty(B, N, Lr, D, device=dev, dtype=T())
+        ops.gemm(att, v_t, out, Lr, N * dh, Lr, batch=(B, H, 1),
+                 a_bs=(H * Lr * Lr, Lr * Lr, 0), a_row=(0, 0, Lr),
+                 b_bs=(N * D * Lr, dh * Lr, 0), b_row=(dh, D * Lr, Lr),
+                 c_bs=(N * Lr * D, dh, 0), c_row=(0, 0, D), c_col=(dh, Lr * D))
         xn_next = ops.linear_residual_ln(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln)
         return att_sym, xn_next
 

@@ -220,6 +220,29 @@ def tied_attention(q, k, v, out, att, w=None, qscale=1.0, att_sym=None, partial_
     return out
 
 
+COUNTERS = {"tied_logits_long": 0}  # launches of paths a test wants to see taken
+
+
+def tied_logits(q, k, att, att_sym=None, qscale=1.0):
+    """Logits + softmax of the tied attention on head-major q / k views [B, N, H, L, 32] (position weights already folded
+    into q): att 16-bit [B, H, L, L], att_sym fp32 [B, L, L, H] or None.  L in {512, 768, 1024} (BASELINE.json configs[3]):
+    contraction-split kernel over 128-query x 256-key tiles with an fp32 workspace (csrc/tied.hip: rf_tied_logits)."""
+    B, N, H, L_, dh = q.shape
+    nsplit = 1
+    while N // nsplit > 64 and N % (2 * nsplit) == 0:
+        nsplit *= 2
+    ws = torch.empty(max(nsplit, 2 if L_ == 256 else 1) * B * H * L_ * L_, device=q.device, dtype=F32)
+    _need_cuda(q, k, att, att_sym, ws)
+    if q.stride() != k.stride():
+        raise ValueError("q and k must share their strides")
+    check(lib.rf_tied_logits(ptr(q), ptr(k), C.byref(_hstrides(q)), None, C.byref(I64x3(0, 0, 0)), float(qscale), ptr(att),
+                             ptr(att_sym), att_sym.shape[-1] if att_sym is not None else 0, B, H, N, L_, dh, ptr(ws), ws.numel(),
+                             stream()), "rf_tied_logits")
+    if L_ > 256:
+        COUNTERS["tied_logits_long"] += 1
+    return att
+
+
 def tied_row_attention(q, k, v):
     """Functional form for the dispatcher op: q, k, v h16 [B, N, L, H, 32] -> (out [B, N, L, H*32], att_sym [B, L, L, H])."""
     B, N, L_, H, dh = q.shape

@@ -78,12 +78,16 @@ def tied_case():
 @pytest.mark.parametrize("mode,tol", [(torch.float32, (2e-5, 2e-5)), (torch.bfloat16, (2e-2, 1.5e-2)), (torch.float16, (4e-3, 3e-3))],
                          ids=["fp32", "bf16", "fp16"])
 def test_tied_row_layer_L1024(tied_case, mode, tol):
+    from rosettafold_pytorch_amd import ops
     m, x, ro, ra = tied_case
     R.set_compute_dtype(mode)
+    before = ops.COUNTERS["tied_logits_long"]
     try:
         out, att = m(x.to(DEV))
     finally:
         R.set_compute_dtype(torch.bfloat16)
+    # the 16-bit modes take the long-row kernel (contraction-split logits over 128 x 256 tiles), not the generic GEMM path
+    assert ops.COUNTERS["tied_logits_long"] - before == (0 if mode == torch.float32 else 1)
     for name, g, r in (("out", out, ro), ("att", att, ra)):
         e, e2 = rel(g, r), rel2(g, r)
         print(f"\n[config4 tied_row_layer.{name} {str(mode).split('.')[-1]}] max-rel {e:.3e}  rel-L2 {e2:.3e}")
