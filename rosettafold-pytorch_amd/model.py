@@ -90,8 +90,12 @@ def pad8(n):
 
 
 def weights_fingerprint(module):
-    """Changes whenever a parameter / buffer of `module` is rebound, moved or edited in place (p.copy_, nn.init.*,
-    optimizer steps bump `_version`; `.data = ...`, `.to()` change `data_ptr`)."""
+    """Changes whenever a parameter / buffer of `module` is rebound, moved or edited in place THROUGH THE TENSOR ITSELF
+    (p.copy_, nn.init.*, optimizer steps bump `_version`; `p.data = other`, `.to()` change `data_ptr`).
+    NOT seen: in-place edits through the `.data` alias (`p.data.copy_(w)`, `p.data.normal_()`, EMA `p.data.lerp_`): `.data`
+    is a detached tensor with a version counter of its own, and a content probe would cost a device read-back per
+    forward.  After such an edit call `invalidate_weight_caches(model)` (tests/test_boundary_gpu.py shows both cases);
+    `load_state_dict`, `load_reference_weights`, `load_checkpoint`, `.to()` and `set_compute_dtype` need nothing."""
     h = 0
     for t in list(module.parameters()) + list(module.buffers()):
         h = (h * 1000003 + t.data_ptr() + 7919 * t._version) & 0xFFFFFFFFFFFFFFF

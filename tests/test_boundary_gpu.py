@@ -202,6 +202,17 @@ def test_load_state_dict_after_forward_is_seen():
     R.invalidate_weight_caches(b)
     got, ref = a(*args), b(*args)
     assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    # edits through the `.data` alias bump neither data_ptr nor _version -- the documented contract is that the
+    # caller invalidates (model.weights_fingerprint); without it the stale copies are used, with it the edit is seen
+    for m in (a, b):
+        for p in m.se3_transformer.parameters():
+            p.data.mul_(0.5)
+    R.invalidate_weight_caches(b)
+    stale, ref = a(*args), b(*args)
+    assert not torch.equal(stale[1], ref[1])
+    R.invalidate_weight_caches(a)
+    got = a(*args)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
 
 
 # ---------------------------------------------------------------- helper kernels
