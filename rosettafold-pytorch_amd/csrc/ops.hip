@@ -750,13 +750,32 @@ __global__ __launch_bounds__(256) void instnorm_apply_vec_kernel(const h16_t* x,
   __syncthreads();
   const int nch = C >> 3;
   const int64_t nchunks = HW * nch;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nchunks; idx += (int64_t)gridDim.x * 256) {
-    const int ch = idx % nch;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  // the host picks a grid whose stride is a multiple of the chunks per pixel whenever it can: every thread then keeps ONE
+  // channel chunk for the whole loop -- scale / shift live in registers and the 64-bit modulo per 16 bytes (which made this
+  // kernel ALU-bound at 2.9 TB/s) disappears
+  const bool fixed = stride % nch == 0;
+  int ch = (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % nch);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = sm[ch * 8 + e];
+    sh[e] = sm[C + ch * 8 + e];
+  }
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < nchunks; idx += stride) {
+    if (!fixed) {
+      ch = (int)(idx % nch);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sc[e] = sm[ch * 8 + e];
+        sh[e] = sm[C + ch * 8 + e];
+      }
+    }
     const int64_t e0 = ((int64_t)b * HW) * C + idx * 8;  // idx = pixel*nch + ch -> element offset pixel*C + ch*8
     const h16x8 v = *(const h16x8*)(x + e0);
     float o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = h2f((h16_t)v[e]) * sm[ch * 8 + e] + sm[C + ch * 8 + e];
+    for (int e = 0; e < 8; ++e) o[e] = h2f((h16_t)v[e]) * sc[e] + sh[e];
     if (residual) {
       const float4 r0 = *(const float4*)(residual + e0), r1 = *(const float4*)(residual + e0 + 4);
       o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w;
@@ -841,7 +860,14 @@ extern "C" int rf_instnorm_apply(const void* x, int x_dtype, const void* sums, c
   const int64_t total = (int64_t)B * HW * C;
   if (x_dtype == RF_H16 && C % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
       (!y2 || ((uintptr_t)y2 % 16) == 0) && (!residual || ((uintptr_t)residual % 16) == 0)) {
-    const unsigned gx = min(cdiv(HW * (C / 8), 256), 4096u);
+    unsigned gx = min(cdiv(HW * (C / 8), 256), 4096u);
+    {  // grid stride (gx * 256 chunks) a multiple of the C / 8 chunks of a pixel: every thread keeps one channel chunk
+      const unsigned nch = (unsigned)(C / 8);
+      unsigned g = nch, r = 256u % nch;
+      while (r) { const unsigned t = g % r; g = r; r = t; }   // gcd(nch, 256)
+      const unsigned m = nch / g;
+      if (gx >= m) gx = gx / m * m;
+    }
     hipLaunchKernelGGL(instnorm_apply_vec_kernel, dim3(gx, B), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream,
                        (const h16_t*)x, (const double*)sums, gamma, beta, eps, residual, act, y, y_dtype, y2, y2_dtype,
                        HW, C);
