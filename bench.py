@@ -90,7 +90,7 @@ def profile_gemms(run):
         esz = 2 if d.ab_dtype == 1 else 4
         k_eff = d.K // 9 if d.a_mode == 1 else d.K  # conv: the image is read once algorithmically
         nbytes = nb * (d.M * k_eff * esz + d.N * d.K * esz + d.M * d.N * (4 if d.c_dtype == 0 else 2)
-                       + (d.M * d.N * 4 if d.residual else 0))
+                       + (d.M * d.N * 4 if d.residual else 0) + (d.M * d.N * 2 if d.ln_out else 0))  # + the fused LayerNorm copy
         recs.append((s, e, 2.0 * d.M * d.N * d.K * nb, int(fam_of()), d.M, d.N, d.K, nb, nbytes))
         return rc
 
