@@ -490,14 +490,17 @@ __device__ unsigned long long g_fv_cycles[8];
 
 // ------------------------------------------------------------------------------------------------------------------
 // 8-wave variant (2 waves per SIMD: a lone wave issues one VALU op per 4 cycles, two co-resident waves one per 2, and
-// the feature maps are VALU-bound).  Phase A: wave = (feature group g = 5,4,4,4 tiles) x (sequence half hs); the two
-// halves' partial contexts are combined through the ctx^T image (half 1 publishes bf16, half 0 adds its fp32 partial
-// and republishes).  Phase B: the sequence is split over all eight waves.  Same maths, operands and LDS image as above.
+// the feature maps are VALU-bound).  Phase A splits the 17 FEATURE tiles over the eight waves (3,2,2,2,2,2,2,2: every wave
+// walks the whole sequence for its own tiles with its Pc fragments resident in registers) -- round 3; rounds 1-2 split
+// (feature group 5,4,4,4) x (sequence half) and combined the halves' partial contexts through the ctx^T image, which cost a
+// publish, a barrier, a read-add-republish and a second barrier per item (6.2k of an item's 23.7k cycles) for a phase-A
+// critical path of 4.5 tile-sequences per SIMD instead of 5.  Phase B: the sequence is split over all eight waves.  Same
+// maths, operands and LDS image as above.
 // ------------------------------------------------------------------------------------------------------------------
 template <int LS, bool SOFTMAX>
 __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAttnP p) {
   constexpr int NSB = LS / 32;                    // s-blocks (pairs of s-tiles) per chunk
-  constexpr int NSBH = NSB / 2;                   // per sequence half
+  constexpr int NJ = 3;                           // feature tiles of a wave in phase A (wave 0: 3, the others 2)
   // s-tiles per wave in phase B: one up to LS = 128 (all eight waves run phase B at LS = 128), two at LS = 256.  Round 2
   // shipped two from LS = 128 up -- only the four older waves ran phase B there, ~13 % slower -- because the one-tile form was
   // not run-to-run reproducible.  Round 3 found the cause (an MFMA result read too early by the denominator shuffle, see
@@ -510,16 +513,13 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
   constexpr int CTX_OFF = V_OFF + LS * 128;
   constexpr int DIAG_OFF = CTX_OFF + FV_DROWS * FV_CTX_LD;
   constexpr int RED_OFF = DIAG_OFF + LS * 4;
-  static_assert(NSB % 2 == 0, "sequence halves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
-  // (feature group, sequence half); waves w and w + 4 share a SIMD: rotating the group of the second half keeps the two
-  // 5-tile waves (g = 0) on different SIMDs (9 + 9 + 8 + 8 tile units instead of 10 + 8 + 8 + 8)
-  const int hs = wave >> 2, g = (wave + hs) & 3;
   const int fr = lane & 15, fq = lane >> 4;
-  const int nm = g == 0 ? 5 : 4;
-  const int m0t = g == 0 ? 0 : 5 + 4 * (g - 1);
+  // this wave's feature tiles in phase A: m0t .. m0t + nm - 1 (waves w and w + 4 share a SIMD: 5 + 4 + 4 + 4 tiles per SIMD)
+  const int nm = wave == 0 ? 3 : 2;
+  const int m0t = wave == 0 ? 0 : 1 + 2 * wave;
   const f32x4 epsv = {p.eps, p.eps, p.eps, p.eps};
   Frag ones;
 #pragma unroll
@@ -583,6 +583,17 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
     first = false;
     fv_lds_barrier();
     FV_STAMP(0)
+    // the Pc fragments of this wave's feature tiles, resident through phase A (swz_off(16 T + fr, c) = 2048 T + swz_off(fr, c))
+    h16x8 pf[NJ][2];
+    {
+      int frP = fr, fqP = fq;
+      asm volatile("" : "+v"(frP), "+v"(fqP));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+          pf[j][kk] = *(const h16x8*)(smem + PC_OFF + m0t * 2048 + swz_off(frP, kk * 4 + fqP) + (j < nm ? j : 0) * 2048);
+    }
     h16x8 qf[STB][2];
     auto load_q = [&](int chunk) {
       int frq = fr, fqq = fq;  // opaque copies: keeps the row / chunk offsets out of the kernel-long live ranges
@@ -616,9 +627,9 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
         }
         ((float*)(smem + DIAG_OFF))[s] = a * (0.0625f * 1.4426950408889634f);
       }
-      // pass 0: global max of the key logits (this wave: its feature tiles x its sequence half)
+      // pass 0: global max of the key logits (this wave: its feature tiles x the whole sequence)
       float mx = -INFINITY;
-      for (int u = hs * NSBH; u < (hs + 1) * NSBH; ++u) {
+      for (int u = 0; u < NSB; ++u) {
         h16x8 kf[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -626,11 +637,9 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
           for (int kk = 0; kk < 2; ++kk)
             kf[t][kk] = *(const h16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + frS, kk * 4 + fqS));
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           if (j < nm) {
-            h16x8 pfj[2];  // (swz_off(16 T + fr, c) = 2048 T + swz_off(fr, c): one lane base + an immediate per tile)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) pfj[kk] = *(const h16x8*)(smem + PC_OFF + m0t * 2048 + swz_off(frS, kk * 4 + fqS) + j * 2048);
+            const h16x8* pfj = pf[j];
             // only feature tile 16 (m = 256..271) holds padded features (a per-tile scalar threshold would live in an SGPR for
             // the whole kernel: the softmax variants spilled them into VGPR lanes)
             const bool valid = (m0t + j) != FV_MT - 1 || frS < FV_M - 16 * (FV_MT - 1);
@@ -652,9 +661,9 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
     }
 
     // ---------------- phase A ----------------
-    f32x4 ctx[5][FV_DT];
+    f32x4 ctx[NJ][FV_DT];
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int i = 0; i < FV_DT; ++i) ctx[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int ck = 0; ck < nch; ++ck) {
@@ -665,27 +674,33 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
       }
-      for (int u = hs * NSBH; u < ((RF_DBG(p.dbg) & 1) ? hs * NSBH : (hs + 1) * NSBH); ++u) {
-        h16x8 kf[2][2];
+      // the K fragments and transposed V fragments of s-block u + 1 are read while s-block u is computed (a wave owns only 2-3
+      // feature tiles: without the read-ahead every s-block starts with an exposed LDS round trip)
+      h16x8 kf[2][2];
+      Frag vf[4];
+      auto load_sblock = [&](int u, h16x8 (&kfo)[2][2], Frag (&vfo)[4]) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk)
-            kf[t][kk] = *(const h16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + fr, kk * 4 + fq));
-        Frag vf[4];
-        {
-          const int p4 = fr & 3;
+            kfo[t][kk] = *(const h16x8*)(smem + K_OFF + swz_off((2 * u + t) * 16 + fr, kk * 4 + fq));
+        const int p4 = fr & 3;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-              const int row = u * 32 + half * 16 + 4 * fq + (fr >> 2);
-              const int off = V_OFF + swz_off(row, i * 2 + (p4 >> 1)) + (p4 & 1) * 8;
-              const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off));
-              vf[i].h[half] = __builtin_bit_cast(uint2, r);
-            }
+          for (int half = 0; half < 2; ++half) {
+            const int row = u * 32 + half * 16 + 4 * fq + (fr >> 2);
+            const int off = V_OFF + swz_off(row, i * 2 + (p4 >> 1)) + (p4 & 1) * 8;
+            const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smem + off));
+            vfo[i].h[half] = __builtin_bit_cast(uint2, r);
           }
         }
+      };
+      load_sblock(0, kf, vf);
+      for (int u = 0; u < ((RF_DBG(p.dbg) & 1) ? 0 : NSB); ++u) {
+        h16x8 kfn[2][2];
+        Frag vfn[4];
+        load_sblock(u + 1 < NSB ? u + 1 : u, kfn, vfn);
         f32x4 init[2] = {epsv, epsv};
         if constexpr (SOFTMAX) {
 #pragma unroll
@@ -695,11 +710,9 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
           }
         }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           if (j < nm) {
-            h16x8 pfj[2];  // re-read per s-block: 8 registers instead of 40 resident ones
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) pfj[kk] = *(const h16x8*)(smem + PC_OFF + m0t * 2048 + swz_off(fr, kk * 4 + fq) + j * 2048);
+            const h16x8* pfj = pf[j];  // resident (24 registers: the accumulators shrank from 5 to 3 tiles)
             f32x4 a[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -733,16 +746,19 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
             ctx[j][4] = rf_mfma16(kfr.v, ones.v, ctx[j][4], 0, 0, 0);
           }
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) kf[t][kk] = kfn[t][kk];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vf[i] = vfn[i];
       }
     }
     FV_STAMP(1)
-    // Combine the two sequence halves through the ctx^T image, the work split between them: feature tiles j = 2, 3 of a
-    // group are finished by the wave of half 1, the others by half 0.  Each wave first publishes its partials of the
-    // tiles its partner finishes, then (after the barrier) adds the partner's partials to its own tiles and republishes.
-    auto mine = [&](int j) { return ((j >> 1) & 1) == hs; };
+    // publish ctx^T (16-bit), rows 0..63 = values, row 64 = k' sums: every wave its own feature tiles, complete
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
-      if (j < nm && !mine(j)) {
+    for (int j = 0; j < NJ; ++j)
+      if (j < nm) {
 #pragma unroll
         for (int i = 0; i < FV_DT; ++i) {
           uint2 w;
@@ -751,7 +767,7 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
           *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq)) = w;
         }
       }
-    fv_lds_barrier();  // every wave is through phase A: the K and V tiles are free again
+    fv_lds_barrier();  // every wave is through phase A: ctx^T is complete, the K and V tiles are free again
     FV_STAMP(2)
     // K/V prefetch of the next item, in flight across the combine and phase B.  (Round 2 had moved it behind the combine's
     // barrier because that made the then unexplained wrong rows rarer: it only shifted the timing of the early MFMA-result
@@ -772,22 +788,6 @@ __global__ __launch_bounds__(512, 1) void favor_attention_kernel8(const FavorAtt
         load_tile8(V_OFF, p.qkv + xb2 + p.v_off, p.x_s, LS_TAG);
       }
     }
-#pragma unroll
-    for (int j = 0; j < 5; ++j)
-      if (j < nm && mine(j)) {
-        // the tile's five partner partials first (independent reads in flight together), then add and republish
-        uint2 o[FV_DT];
-#pragma unroll
-        for (int i = 0; i < FV_DT; ++i) o[i] = *(const uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq));
-#pragma unroll
-        for (int i = 0; i < FV_DT; ++i) {
-          uint2 w;
-          w.x = pack2(FV_CS(ctx[j][i][0]) + rf_h16_lo(o[i].x), FV_CS(ctx[j][i][1]) + rf_h16_hi(o[i].x));
-          w.y = pack2(FV_CS(ctx[j][i][2]) + rf_h16_lo(o[i].y), FV_CS(ctx[j][i][3]) + rf_h16_hi(o[i].y));
-          *(uint2*)(smem + CTX_OFF + (i * 16 + fr) * FV_CTX_LD + ctx_col(m0t + j, fq)) = w;
-        }
-      }
-    fv_lds_barrier();  // ctx^T complete
     FV_STAMP(3)
     // ---------------- phase B ----------------
     for (int qc = 0; qc < nch; ++qc) {
