@@ -209,6 +209,15 @@ int rf_poswise_collapsed(const void* xn, const void* u, float* w, int B, int N, 
 int rf_outer_product_ln_linear(const void* xt, const void* yt, const void* wprime, const float* s, const float* c, float* out,
                                int B, int L, int N, int P, int Dout, float eps, const float* ln2_gamma, const float* ln2_beta,
                                float ln2_eps, void* y, int64_t y_ld, void* stream);
+
+/* The same operator, second kernel (csrc/outer_pairs.hip: a wave owns residue pairs, the 1024-wide block never leaves its
+ * registers; opt-in in the Python layer, RF_OUTER_PAIRS=1: it ties with the first kernel).  Same arguments except the weight layout: w_packed = W * gamma (16-bit) in the
+ * order the kernel streams it, [32 v][18 o-tiles][64 lanes][8]: element e of lane 16 fq + fr = W'[16 ot + fr][(16 (e >> 2) +
+ * 4 fq + (e & 3)) * 32 + v] (feature index k = u * 32 + v as in rf.py:416).  Dout = 288, P = 32, N in {64, 128}, L % 16 == 0.
+ * y (when given): 8-byte aligned, y_ld % 4 == 0. */
+int rf_outer_product_pairs(const void* xt, const void* yt, const void* w_packed, const float* s, const float* c, float* out,
+                           int B, int L, int N, int P, int Dout, float eps, const float* ln2_gamma, const float* ln2_beta,
+                           float ln2_eps, void* y, int64_t y_ld, void* stream);
 /* Optional tail (PairUpdateWithMsa.ln_coevol_feat, rf.py:443,486): with y != NULL the kernel applies a second LayerNorm
  * (ln2_gamma / ln2_beta [Dout], ln2_eps) over the Dout outputs of every pair and writes 16-bit y[(b,i,j) * y_ld + o] INSTEAD of
  * `out` (which may then be NULL): the fp32 result and the separate LayerNorm pass over it disappear as well.  y: 16-byte

@@ -54,6 +54,7 @@ PROTOTYPES = {
                           C.POINTER(I64x4), i32, i32, i32, i32, i32, vp, i64, vp],
     "rf_ffn_fused": [vp, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, f32, i64, i32, i32, vp],
     "rf_outer_product_ln_linear": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, f32, vp, i64, vp],
+    "rf_outer_product_pairs": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, f32, vp, i64, vp],
     "rf_poswise_collapsed": [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp],
     "rf_poswise": [vp, i32, i64, vp, i64, i32, i32, i32, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, f32, f32, vp],
     "rf_weighted_msa_sum": [vp, i32, vp, vp, i64, i32, i32, i32, i32, vp],

@@ -254,10 +254,17 @@ def tied_row_attention(q, k, v):
     return out, sym
 
 
+# csrc/outer_pairs.hip ("pairs in registers": the 1024-wide block never leaves a wave's registers) is correct and ties with
+# csrc/outer.hip (column split, block through LDS) with the consumer's LayerNorm fused (371 vs 355-367 us) and loses without it
+# (370 vs 327 us): both are bound by the rate at which a CU issues its global_load_lds pieces, not by the matrix pipe
+# (DESIGN.md section 5).  Opt-in: RF_OUTER_PAIRS=1.
+OUTER_PAIRS = bool(int(__import__("os").environ.get("RF_OUTER_PAIRS", "0")))
+
+
 def outer_fused(xt, yt, wprime, s, c, out, eps, ln2=None):
-    """Fused OuterProductMean core (csrc/outer.hip): xt, yt bf16 [B, L, 32, N]; wprime bf16 [16, Dout, 64] (outer_fold's chunk-major
-    layout); out fp32 [B,L,L,Dout].
-    ln2 = (gamma, beta, eps, y, y_ld): also apply LayerNorm over Dout and write bf16 y[(b,i,j) * y_ld + o] instead of `out`."""
+    """Fused OuterProductMean core: xt, yt 16-bit [B, L, 32, N]; wprime from outer_fold -- step-major [32, 18, 64, 8]
+    (csrc/outer_pairs.hip: pairs in registers, opt-in) or chunk-major [16, Dout, 64] (csrc/outer.hip, the default); out fp32 [B,L,L,Dout].
+    ln2 = (gamma, beta, eps, y, y_ld): also apply LayerNorm over Dout and write 16-bit y[(b,i,j) * y_ld + o] instead of `out`."""
     B, L_, P, N = xt.shape
     _need_cuda(xt, yt, wprime, s, c, out)
     g2 = b2 = y = None
@@ -265,23 +272,35 @@ def outer_fused(xt, yt, wprime, s, c, out, eps, ln2=None):
     if ln2 is not None:
         g2, b2, eps2, y, y_ld = ln2
         _need_cuda(g2, b2, y)
+    if wprime.dim() == 4 and tuple(wprime.shape) == (32, 18, 64, 8):
+        check(lib.rf_outer_product_pairs(ptr(xt), ptr(yt), ptr(wprime), ptr(s), ptr(c), ptr(out), B, L_, N, P, 288,
+                                         float(eps), ptr(g2), ptr(b2), float(eps2), ptr(y), int(y_ld), stream()),
+              "rf_outer_product_pairs")
+        return y if ln2 is not None else out
     if wprime.dim() != 3 or wprime.shape[0] != 16 or wprime.shape[2] != 64:
-        raise ValueError("outer_fused: wprime must come from outer_fold (chunk-major [16, Dout, 64])")
+        raise ValueError("outer_fused: wprime must come from outer_fold (step-major [32, 18, 64, 8] or chunk-major [16, Dout, 64])")
     check(lib.rf_outer_product_ln_linear(ptr(xt), ptr(yt), ptr(wprime), ptr(s), ptr(c), ptr(out), B, L_, N, P, wprime.shape[1],
                                          float(eps), ptr(g2), ptr(b2), float(eps2), ptr(y), int(y_ld), stream()),
           "rf_outer_product_ln_linear")
     return y if ln2 is not None else out
 
 
-def outer_fold(w, gamma, beta, bias, dtype=None):
-    """(W * gamma in the 16-bit type, its fp32 row sums, W beta + bias): the LayerNorm(1024) affine folded into Linear(1024 -> Dout)."""
+def outer_fold(w, gamma, beta, bias, dtype=None, pairs=None):
+    """(W * gamma in the 16-bit type in kernel layout, its fp32 row sums, W beta + bias): the LayerNorm(1024) affine folded into
+    Linear(1024 -> Dout).  pairs (default OUTER_PAIRS, Dout = 288 only): the fragment order csrc/outer_pairs.hip streams,
+    [32 v][18 o-tiles][64 lanes][8]: element e of lane 16 fq + fr = W'[16 ot + fr][(16 (e >> 2) + 4 fq + (e & 3)) * 32 + v]."""
     wp = (w.float() * gamma.float()[None, :]).to(dtype or h16()).contiguous()
     s = wp.float().sum(1).contiguous()
-    # kernel layout: chunk-major [16 chunks = (ug, vg)][Dout][64 = (uu, vv)] with feature k = (8 ug + uu) * 32 + 8 vg + vv: the 64
-    # features a chunk of the fused kernel contracts over are one 128-byte line per output column (csrc/outer.hip)
     Dout = wp.shape[0]
+    c = (w.float() @ beta.float() + bias.float()).contiguous()
+    if (OUTER_PAIRS if pairs is None else pairs) and Dout == 288:
+        # W'[o = (ot, fr)][k = (u = (hsel, fq, jj), v)] -> [v][ot][fq][fr][hsel][jj]
+        wq = wp.view(18, 16, 2, 4, 4, 32).permute(5, 0, 3, 1, 2, 4).contiguous().view(32, 18, 64, 8)
+        return wq, s, c
+    # chunk-major [16 chunks = (ug, vg)][Dout][64 = (uu, vv)] with feature k = (8 ug + uu) * 32 + 8 vg + vv: the 64 features a
+    # chunk of csrc/outer.hip contracts over are one 128-byte line per output column
     wpc = wp.view(Dout, 4, 8, 4, 8).permute(1, 3, 0, 2, 4).contiguous().view(16, Dout, 64)
-    return wpc, s, (w.float() @ beta.float() + bias.float()).contiguous()
+    return wpc, s, c
 
 
 def outer_product_ln_linear(x, y, gamma, beta, w, b, eps):

@@ -451,11 +451,13 @@ def test_gemm_persistent_split_c(N, BNexp):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("pairs", [False, True], ids=["column-split", "pairs-in-registers"])
 @pytest.mark.parametrize("B,N,Lr", [(1, 128, 16), (2, 128, 48), (1, 64, 32)])
-def test_outer_product_fused(B, N, Lr):
+def test_outer_product_fused(B, N, Lr, pairs):
     """Fused OuterProductMean (csrc/outer.hip): outer product over the MSA depth -> LayerNorm(1024) -> Linear(1024 -> 288) in
     one kernel, against einsum + layer_norm + linear in fp32 on the same bf16 inputs (rf.py:412-427)."""
     P, Dout = 32, 288
+    ops.OUTER_PAIRS = pairs  # both fused kernels: csrc/outer_pairs.hip (pairs in registers) and csrc/outer.hip (column split)
     x, y = randn(B, N, Lr, P).bfloat16(), (randn(B, N, Lr, P, seed=1) * 0.3).bfloat16()
     g_, b_ = 1.0 + 0.2 * randn(P * P, seed=2), 0.1 * randn(P * P, seed=3)
     w, bias = randn(Dout, P * P, seed=4) * 0.05, randn(Dout, seed=5)
@@ -484,6 +486,7 @@ def test_outer_product_fused(B, N, Lr):
     import rosettafold_pytorch_amd.custom_ops  # noqa: F401
     out2 = torch.ops.rfmi.outer_product_ln_linear(x, y, g_, b_, w, bias, 1e-5)
     assert rel_err(out2, torch.nn.functional.linear(torch.nn.functional.layer_norm(co, (P * P,), g_, b_, 1e-5), w, bias)) < 1.5e-2
+    ops.OUTER_PAIRS = False
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])

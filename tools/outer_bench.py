@@ -33,3 +33,13 @@ feat = torch.empty(B, L, L, 720, device="cuda", dtype=torch.bfloat16)
 t = timeit(lambda: m.run_into(xt, yt, ln2, feat, 720))
 t_ln = timeit(lambda: R.model.ln(ln2, a, out=feat, out_ld=720, out_off=0))
 print(f"fused + LayerNorm(288) epilogue -> feat: {t*1e3:.1f} us (separate LayerNorm launch it replaces: {t_ln*1e3:.1f} us)")
+# the two fused kernels side by side (csrc/outer_pairs.hip = default, csrc/outer.hip = RF_OUTER_CHUNKS=1)
+for pairs in (True, False):
+    ops.OUTER_PAIRS = pairs
+    R.invalidate_weight_caches(m)
+    t = timeit(lambda: m.run(xt, yt, N))
+    t2 = timeit(lambda: m.run_into(xt, yt, ln2, feat, 720))
+    o = m.run(xt, yt, N)
+    print(f"{'pairs-in-registers' if pairs else 'column-split (round 2/3a)'} kernel: {t*1e3:.1f} us fp32 rows ({fl/t/1e9:.0f} TF/s), {t2*1e3:.1f} us with LayerNorm(288)"
+          f"  | vs two-GEMM path max-rel {((o - b).abs().max() / b.abs().max()).item():.2e}")
+ops.OUTER_PAIRS = True
