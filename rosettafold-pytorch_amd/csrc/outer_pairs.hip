@@ -84,36 +84,42 @@ __device__ __forceinline__ op_u32x2 op_lds_read8(unsigned addr) {
 #endif
 
 // NKS = N / 32 (stage-1 K steps): 4 (N = 128) or 2 (N = 64)
-template <int NKS, bool LN2>
-__global__ __launch_bounds__(512) void outer_pairs_kernel(const OPairsP p) {
+// NW = waves per workgroup: 8 (one workgroup per CU, tile = 8 residues x 16) or 4 (TWO independent workgroups per CU, tile = 4 x 16:
+// the two waves of a SIMD then belong to different barrier domains and drift out of phase, so one computes while the other
+// waits, packs or issues DMAs -- with one 8-wave workgroup both sit in the same phase at the same time).
+template <int NKS, bool LN2, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void outer_pairs_kernel(const OPairsP p) {
 #ifdef OP_STAMP
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #endif
   constexpr int NT = 18, NTH = 9;             // 16-wide output tiles: all / per wave
   constexpr int NV = 32;                      // steps (one v each)
-  constexpr int PIECES = 24, SLOT = PIECES * 1024, PD = 3;   // 1 KB pieces per slot: [0, NKS) y slice, [4, 22) W' slice
+  constexpr int HW = NW / 2;                  // residue pairs per tile
+  constexpr int PIECES = NW == 8 ? 24 : 22, SLOT = PIECES * 1024, PD = (PIECES + NW - 1) / NW;   // 1 KB pieces per slot: [0, NKS) y slice, [4, 22) W' slice
   constexpr int WOFF = 4;                     // first W' piece of a slot
-  constexpr int NSTG = 5;
+  constexpr int NSTG = NW == 8 ? 5 : 3;
   constexpr int DUMP = NSTG * SLOT;
-  constexpr int XB_OFF = DUMP + 1024;         // [2 parities][8 waves][1 KB]: lane-for-lane exchange between the two waves of a residue pair
+  constexpr int XB_OFF = DUMP + 1024;         // [2 parities][NW waves][1 KB]: lane-for-lane exchange between the two waves of a residue pair
+  constexpr int XBP = NW * 1024;              // one parity block
   constexpr int XP = 2 * NKS;                 // x fragments of a wave (pieces of its residue): piece f = ut * NKS + ks
   constexpr int CPIECES = 5;                  // constants: s | c | gamma2 | beta2 (4 x 288 fp32 = 4608 bytes)
-  constexpr int SPT = 4 + NV + 1 + 1;         // ring steps per tile: x slots, steps v = 0 .. 32 (the last: stage 2 only), constants
+  constexpr int NXS = NW / 2;                 // x slots per tile (two waves each)
+  constexpr int SPT = NXS + NV + 1 + 1;       // ring steps per tile: x slots, steps v = 0 .. 32 (the last: stage 2 only), constants
   constexpr int PF = 3;                       // W' fragment reads in flight ahead of the MFMAs that use them
   constexpr int N = NKS * 32;
   constexpr int S1 = 2 * NTH;                 // posted stores per wave and tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = wave & 3, ch = wave >> 2;
+  const int g = wave % HW, ch = wave / HW;
   const int fr = lane & 15, fq = lane >> 4;
 
   // tile t -> (b, jt, it), it fastest
-  auto tile_ij = [&](int t, int& b, int& i0, int& j0) {
+  auto tile_ij = [&](int t, int& b, int& i0, int& j0) __attribute__((always_inline)) {
     const int it = t % p.it_n, r = t / p.it_n;
     const int jt = r % p.jt_n;
     b = r / p.jt_n;
-    i0 = it * 8;
+    i0 = it * NW;
     j0 = jt * 16;
   };
 
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(512) void outer_pairs_kernel(const OPairsP p) {
   const h16_t* f_x = p.xt;   // this lane's x source of the cursor's tile: xt[b, i0, fr, 8 fq ..]
   const h16_t* f_y = p.yt;   // yt[b, j0 + fr, v, 8 fq ..] of the cursor's step
   const h16_t* f_w = p.wq;   // W' slice of step v - 1, this lane's 16 bytes of piece 0
-  auto prep = [&]() {
+  auto prep = [&]() __attribute__((always_inline)) {
     const int tile = blockIdx.x + f_it * gridDim.x;
     i_dst = smem + f_slot * SLOT;
     if (++f_slot == NSTG) f_slot = 0;
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(512) void outer_pairs_kernel(const OPairsP p) {
       f_y = p.yt + (((int64_t)b * p.L + j0 + fr) * 32) * N + fq * 8;
       f_w = p.wq + lane * 8;
       i_kind = 0;
-    } else if (f_pos < 4) {
+    } else if (f_pos < NXS) {
       i_kind = 0;
     } else if (f_pos < SPT - 1) {
       i_kind = 1;
@@ -159,19 +165,19 @@ __global__ __launch_bounds__(512) void outer_pairs_kernel(const OPairsP p) {
     }
   };
   // after the three DMAs of a step slot: the cursor's pointers move to the next v
-  auto advance = [&]() {
+  auto advance = [&]() __attribute__((always_inline)) {
     if (i_kind == 1) {
-      if (i_pos > 4) f_w += NT * 512;   // (the slot of v = 0 carries no W')
+      if (i_pos > NXS) f_w += NT * 512;   // (the slot of v = 0 carries no W')
       f_y += N;
     }
   };
-  auto dma = [&](auto tc) {
+  auto dma = [&](auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value;
-    const int q = t * 8 + wave;  // piece of the slot this wave issues (24 pieces, 3 per wave)
+    const int q = t * NW + wave;  // piece of the slot this wave issues
     if (i_kind == 1) {
-      if (q < NKS && i_pos < 4 + NV) {
+      if (q < NKS && i_pos < NXS + NV) {
         op_glds16(f_y + q * 32, i_dst + q * 1024);
-      } else if (q >= WOFF && q < WOFF + NT && i_pos > 4) {
+      } else if (q >= WOFF && q < WOFF + NT && i_pos > NXS) {
         op_glds16(f_w + (q - WOFF) * 512, i_dst + q * 1024);
       } else {
         op_glds16(p.wq, smem + DUMP);  // every wave issues PD instructions per step: the counted vmcnt relies on it
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(512) void outer_pairs_kernel(const OPairsP p) {
       const int w = 2 * i_pos + (q >= XP ? 1 : 0), f = q >= XP ? q - XP : q;
       if (q < 2 * XP) {
         // residue i0 + 2 (w & 3) + (w >> 2), piece f = (ut, ks): + ((i - i0) * 32 + 16 ut) * N + 32 ks elements
-        op_glds16(f_x + ((2 * (w & 3) + (w >> 2)) * 32 + (f / NKS) * 16) * N + (f % NKS) * 32, i_dst + q * 1024);
+        op_glds16(f_x + ((2 * (w % HW) + (w / HW)) * 32 + (f / NKS) * 16) * N + (f % NKS) * 32, i_dst + q * 1024);
       } else {
         op_glds16(p.wq, smem + DUMP);
       }
@@ -195,16 +201,22 @@ __global__ __launch_bounds__(512) void outer_pairs_kernel(const OPairsP p) {
       op_glds16(p.wq, smem + DUMP);
     }
   };
-  auto dma_all = [&]() {
+  auto dma_all = [&]() __attribute__((always_inline)) {
     dma(std::integral_constant<int, 0>{});
     dma(std::integral_constant<int, 1>{});
     dma(std::integral_constant<int, 2>{});
+    if constexpr (PD > 3) {
+      dma(std::integral_constant<int, 3>{});
+      dma(std::integral_constant<int, 4>{});
+      dma(std::integral_constant<int, 5>{});
+    }
+    static_assert(PD == 3 || PD == 6, "pieces per wave and step");
   };
 
   // ---- consumer side (counted waits as in csrc/ffn.hip: besides its DMAs a wave only has the posted stores of its epilogue) ----
   constexpr int WAIT0 = PD * (NSTG - 2), WAIT1 = WAIT0 + S1;
   int c_slot = 0, post = 0;
-  auto step = [&]() -> unsigned {
+  auto step = [&]() __attribute__((always_inline)) -> unsigned {
     if (post > 0) {
       --post;
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT1) : "memory");
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(512) void outer_pairs_kernel(const OPairsP p) {
     if (++c_slot == NSTG) c_slot = 0;
     return st;
   };
-  const unsigned xb_own = (unsigned)(XB_OFF + wave * 1024 + lane * 16), xb_oth = (unsigned)(XB_OFF + (wave ^ 4) * 1024 + lane * 16);
+  const unsigned xb_own = (unsigned)(XB_OFF + wave * 1024 + lane * 16), xb_oth = (unsigned)(XB_OFF + (wave ^ HW) * 1024 + lane * 16);
 
 #pragma unroll 1
   for (int s_ = 0; s_ < NSTG - 1; ++s_) {
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(512) void outer_pairs_kernel(const OPairsP p) {
     // ---- x fragments of this wave's residue: MFMA-A, rows u (two tiles of 16), K = n ------------------------------------
     h16x8 xa[2][NKS];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NXS; ++k) {
       const unsigned st = step();
       dma_all();
       if (k == (wave >> 1)) {
@@ -264,12 +276,13 @@ __global__ __launch_bounds__(512) void outer_pairs_kernel(const OPairsP p) {
       OpFrag oth;
       h16x8 a[PF], yb[NKS];
       const unsigned wst = st + (WOFF + ch * NTH) * 1024;
-      OP_RD(oth.v, xb_oth + ((v - 1) & 1) * 8192, 0);
+      OP_RD(oth.v, xb_oth + ((v - 1) & 1) * XBP, 0);
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) OP_RD(yb[ks], st, ks * 1024);
 #pragma unroll
       for (int k = 0; k < PF; ++k) OP_RD(a[k], wst, k * 1024);
       OP_LANDED(NKS + PF, oth.v);
+      OP_T(6)
       const h16x8 hf0 = ch ? oth.v : own.v, hf1 = ch ? own.v : oth.v;  // residue i0 + 2 g (computed by ch = 0), i0 + 2 g + 1
       f32x4 d[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
       // (at v = 0 the slot holds no W' and `own` / `oth` are stale: the stage-2 products are multiplied away by zeroed
@@ -290,9 +303,18 @@ __global__ __launch_bounds__(512) void outer_pairs_kernel(const OPairsP p) {
           d[k & 1] = rf_mfma16(xa[k & 1][k >> 1], yb[k >> 1], d[k & 1], 0, 0, 0);
         }
         if (k + PF < NTH) OP_RD(a[k % PF], wst, (k + PF) * 1024);
-        if (k == 1) dma(std::integral_constant<int, 0>{});
-        if (k == 4) dma(std::integral_constant<int, 1>{});
-        if (k == 7) dma(std::integral_constant<int, 2>{});
+        if constexpr (PD == 3) {
+          if (k == 1) dma(std::integral_constant<int, 0>{});
+          if (k == 4) dma(std::integral_constant<int, 1>{});
+          if (k == 7) dma(std::integral_constant<int, 2>{});
+        } else {
+          if (k == 0) dma(std::integral_constant<int, 0>{});
+          if (k == 2) dma(std::integral_constant<int, 1>{});
+          if (k == 3) dma(std::integral_constant<int, 2>{});
+          if (k == 5) dma(std::integral_constant<int, 3>{});
+          if (k == 6) dma(std::integral_constant<int, 4>{});
+          if (k == 8) dma(std::integral_constant<int, (PD > 3 ? 5 : 0)>{});
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       static_assert(2 * NKS <= NTH, "stage-1 MFMAs ride in the stage-2 loop");
@@ -308,7 +330,7 @@ __global__ __launch_bounds__(512) void outer_pairs_kernel(const OPairsP p) {
         own.u[1] = rf_pack2_h16(d[0][2], d[0][3]);
         own.u[2] = rf_pack2_h16(d[1][0], d[1][1]);
         own.u[3] = rf_pack2_h16(d[1][2], d[1][3]);
-        op_lds_write16(xb_own + (v & 1) * 8192, own.q);
+        op_lds_write16(xb_own + (v & 1) * XBP, own.q);
       }
       OP_T(4)
     }
@@ -385,10 +407,10 @@ __global__ __launch_bounds__(512) void outer_pairs_kernel(const OPairsP p) {
         q += __shfl_xor(q, 32, 64);
         sq[tt] = q;
       }
-      op_lds_write8(xb_own + 8192, sq[0], sq[1]);  // (the other parity block: the partner may still be reading the first exchange)
+      op_lds_write8(xb_own + XBP, sq[0], sq[1]);  // (the other parity block: the partner may still be reading the first exchange)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      const op_u32x2 o3 = op_lds_read8(xb_oth + 8192);
+      const op_u32x2 o3 = op_lds_read8(xb_oth + XBP);
       const float r2[2] = {rsqrtf((sq[0] + __uint_as_float(o3.x)) * (1.f / 288.f) + p.eps2),
                            rsqrtf((sq[1] + __uint_as_float(o3.y)) * (1.f / 288.f) + p.eps2)};
 #pragma unroll
@@ -427,20 +449,28 @@ __global__ __launch_bounds__(512) void outer_pairs_kernel(const OPairsP p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int NKS, bool LN2>
-static int launch_outer_pairs(OPairsP& p, hipStream_t s) {
-  constexpr size_t lds = 5 * 24 * 1024 + 1024 + 16384;
+template <int NKS, bool LN2, int NW>
+static int launch_outer_pairs_nw(OPairsP& p, hipStream_t s) {
+  constexpr size_t lds = (size_t)(NW == 8 ? 5 * 24 : 3 * 22) * 1024 + 1024 + 2 * NW * 1024;
   const int ncu = rf_num_cus();
   if (ncu <= 0) return RF_EINVAL;
-  p.it_n = p.L / 8;
+  if (p.L % NW) return RF_EINVAL;
+  p.it_n = p.L / NW;
   p.jt_n = p.L / 16;
   const int64_t nt = (int64_t)p.B * p.it_n * p.jt_n;
   if (nt > 0x7fffffffLL) return RF_EINVAL;
   p.ntiles = (int)nt;
-  const int grid = p.ntiles < ncu ? p.ntiles : ncu;
-  if (const int e = rf_enable_big_lds<outer_pairs_kernel<NKS, LN2>>()) return e;
-  hipLaunchKernelGGL((outer_pairs_kernel<NKS, LN2>), dim3((unsigned)grid), dim3(512), lds, s, p);
+  const int slots = (NW == 8 ? 1 : 2) * ncu;  // workgroups resident at once
+  const int grid = p.ntiles < slots ? p.ntiles : slots;
+  if (const int e = rf_enable_big_lds<outer_pairs_kernel<NKS, LN2, NW>>()) return e;
+  hipLaunchKernelGGL((outer_pairs_kernel<NKS, LN2, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, s, p);
   return rf_launch_status();
+}
+
+template <int NKS, bool LN2>
+static int launch_outer_pairs(OPairsP& p, hipStream_t s) {
+  static const int nw = getenv("RF_OUTER_PAIRS_NW") ? atoi(getenv("RF_OUTER_PAIRS_NW")) : 8;  // (A/B: 4 = two 4-wave workgroups per CU: measured slower, 418-439 vs 346-364 us)
+  return nw == 8 ? launch_outer_pairs_nw<NKS, LN2, 8>(p, s) : launch_outer_pairs_nw<NKS, LN2, 4>(p, s);
 }
 
 // include/rfmi.h: rf_outer_product_pairs

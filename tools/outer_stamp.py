@@ -11,7 +11,7 @@ yt = (torch.randn(B, L, P, N, device="cuda") * 0.05).bfloat16()
 o = m.run(xt, yt, N); torch.cuda.synchronize()
 o = m.run(xt, yt, N); torch.cuda.synchronize()
 t = o.view(-1)[:32].view(torch.int64).cpu().tolist()
-names = ["stage 1 tail + vmcnt wait", "lgkm + barrier", "prep", "stage 2 (+ its DMAs)", "stage 1 + exchange write", "epilogue"]
+names = ["vmcnt wait", "lgkm + barrier", "prep", "MFMA interval (26 MFMAs + 3 DMAs)", "statistics + pack + exchange write", "epilogue", "first fragments landed (issue 8 reads, wait for the partner fragment)"]
 for w, base in ((0, 0), (7, 8)):
-    tot = sum(t[base:base + 6])
-    print(f"wave {w}: total {tot / 1e3:.0f}k cycles: " + ", ".join(f"{n} {100 * v / tot:.1f}%" for n, v in zip(names, t[base:base + 6])))
+    tot = sum(t[base:base + 7])
+    print(f"wave {w}: total {tot / 1e3:.0f}k cycles: " + ", ".join(f"{n} {100 * v / tot:.1f}%" for n, v in zip(names, t[base:base + 7])))
