@@ -128,6 +128,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
   if constexpr (LN) {
     for (int i = tid; i < 2 * BN; i += 512) ((float*)(smem + GB_OFF))[i] = i < BN ? p.ln_gamma[i] : p.ln_beta[i - BN];
   }
+  // the bias row (N <= 384 floats) lives in LDS: read from global at every tile's accumulator init, its per-lane pointer was
+  // spilled to scratch by hipcc and every reload came with an s_waitcnt vmcnt(0) -- nine serialised round trips per tile
+  constexpr int BIAS_OFF = GB_OFF + (LN ? 2 * BN * 4 : 0);
+  for (int i = tid; i < p.tilesN * BN; i += 512) ((float*)(smem + BIAS_OFF))[i] = (p.bias && i < p.N) ? p.bias[i] : 0.f;
+  __syncthreads();  // (before any DMA is in flight)
 
   // ---- persistent tile walk ----------------------------------------------------------------------------------
   // slot: XCD-aware position of this workgroup inside a round of gridDim.x tiles (workgroups b and b+8 share an XCD
@@ -156,8 +161,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fast_kernel(const FastP p) {
     f32x4 acc[WM][WN];
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-      f32x4 bc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bc = *(const f32x4*)(p.bias + n0 + wn * TN + j * 16 + 4 * fq);
+      const f32x4 bc = *(const f32x4*)(smem + BIAS_OFF + (n0 + wn * TN + j * 16 + 4 * fq) * 4);
 #pragma unroll
       for (int i = 0; i < WM; ++i) acc[i][j] = bc;
     }
@@ -455,7 +459,7 @@ static int launch_fast(const FastP& p, hipStream_t s) {
   const int n_cu = rf_num_cus();
   if (n_cu <= 0) return RF_EINVAL;
   const int grid = p.ntiles < n_cu ? p.ntiles : n_cu;
-  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), 2 * STAGE + (LN ? 2 * BN * 4 : 0), s, p);
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), 2 * STAGE + (LN ? 2 * BN * 4 : 0) + (size_t)p.tilesN * BN * 4, s, p);
   return rf_launch_status();
 }
 
