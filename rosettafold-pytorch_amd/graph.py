@@ -41,6 +41,7 @@ class GraphedForward:
     def recapture(self, monotonic=None):
         """(Re)record the graph: after load_state_dict / set_compute_dtype, or for the other residue-index branch."""
         with torch.cuda.device(self.device), torch.no_grad():
+            self._dtype = M.T()   # the graph holds the kernels of the library active now
             self._mono = self._validate(*self._in) if monotonic is None else monotonic
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -61,6 +62,8 @@ class GraphedForward:
             if new.shape != static.shape or new.dtype != static.dtype or new.device != static.device:
                 raise ValueError(f"GraphedForward was captured for {tuple(static.shape)} {static.dtype} on {static.device}; "
                                  f"got {tuple(new.shape)} {new.dtype} on {new.device}")
+        if M.T() != self._dtype:
+            raise L.RfmiError(f"GraphedForward was captured in {self._dtype} mode; set_compute_dtype changed it to {M.T()}: call recapture()")
         with torch.cuda.device(self.device):
             msa, seq, aa_idx = msa.contiguous(), seq.contiguous(), aa_idx.contiguous()
             mono = self._validate(msa, seq, aa_idx)   # IndexError before anything is overwritten

@@ -53,6 +53,12 @@ def test_graph_keeps_the_boundary_checks():
         g(bad, a[1], a[2])
     with pytest.raises(ValueError, match="captured for"):
         g(*inputs(0, L=32))
+    R.set_compute_dtype(torch.float16)       # the graph holds the other library's kernels: refused until recaptured
+    try:
+        with pytest.raises(R._lib.RfmiError, match="recapture"):
+            g(*a)
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
     assert all(torch.equal(x, y) for x, y in zip(flat(g(*a)), good))   # a refused call leaves the graph usable
     # unordered residue indices: the structure track needs the general edge capacity -> re-captured, equals eager
     aa = a[2].clone()
