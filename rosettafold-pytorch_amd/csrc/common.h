@@ -154,4 +154,5 @@ static inline bool rf_env_flag(const char* name) { return getenv(name) != nullpt
 int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream);
 // gemm_wreg.hip: skinny-K (K = 288 / 384) projection GEMM with register-resident weights; same return convention
 int rf_gemm_wreg_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream);
+int rf_conv288_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream);  // csrc/conv288.hip
 void rf_gemm_fast_set_stamps(void* buf);

@@ -801,6 +801,10 @@ extern "C" int rf_gemm(const rf_gemm_desc* dd, void* stream) {
   }
   if (d.tile_cfg == 0 && !p.dbg && !p.stamps) {  // (stamps of the generic kernel: keep it on the generic kernel)
     int rc = 0;
+    if (d.a_mode == RF_AMODE_CONV3X3 && !want_ln && rf_conv288_try(d, batch, &rc, stream)) {
+      g_last_family = 2;
+      return rc;
+    }
     if (rf_gemm_wreg_try(d, batch, &rc, stream)) {
       g_last_family = 4;
       return rc;

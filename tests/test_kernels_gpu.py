@@ -287,6 +287,33 @@ def test_conv3x3(dtype, tol, dil):
     assert rel_err(out, ref.permute(0, 2, 3, 1)) < tol
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("dil,Hh,Ww,bias", [(1, 12, 256, False), (2, 9, 256, True), (4, 20, 256, False), (8, 18, 512, True)])
+def test_conv3x3_c288_halo_kernel(dil, Hh, Ww, bias, dt):
+    """csrc/conv288.hip (the ResNet pair refiner's 288 -> 288 channel convolutions on rows of whole 256-pixel tiles: the
+    three column taps of a row tap read one haloed LDS image) against conv2d, and bit for bit against the generic
+    implicit-GEMM kernel (same MFMA products, same fp32 accumulation order per output up to the tap order)."""
+    import rosettafold_pytorch_amd as R
+    R.set_compute_dtype(dt)
+    try:
+        B, C = 2, 288
+        x = (randn(B, Hh, Ww, C) * 0.5).to(dt)
+        w = (randn(C, C, 3, 3, seed=1) * 0.05).to(dt)
+        b = randn(C, seed=2) if bias else None
+        ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b, padding="same", dilation=dil).permute(0, 2, 3, 1)
+        wk = w.permute(0, 2, 3, 1).reshape(C, 9 * C).contiguous()
+        out = torch.empty(B, Hh, Ww, C, device=DEV, dtype=dt)
+        ops.gemm(x, wk, out, B * Hh * Ww, C, 9 * C, conv=(B, Hh, Ww, C, dil), bias=b)
+        assert L.lib.rf_gemm_last_family() == 2
+        tol = 1.0 if dt == torch.bfloat16 else 0.15
+        assert rel_err(out, ref) < 1.2e-2 * tol
+        out2 = torch.empty_like(out)          # tile_cfg pins the generic kernel (256 x 288 x 64 tiles)
+        ops.gemm(x, wk, out2, B * Hh * Ww, C, 9 * C, conv=(B, Hh, Ww, C, dil), bias=b, tile_cfg=14)
+        assert rel_err(out, out2) < 1e-2 * tol   # both round the same fp32 sums (in a different order) to 16 bits
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+
+
 def test_relu_eps_epilogue():
     M, N, K = 70, 288, 64
     x, w = randn(M, K, dtype=torch.bfloat16), randn(N, K, dtype=torch.bfloat16, seed=1)

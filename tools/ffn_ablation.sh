@@ -7,5 +7,5 @@ cd "$(dirname "$0")/../rosettafold-pytorch_amd/csrc"
 make -j8 >/dev/null
 for v in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -Wno-unused-value -DFFN_ABL=$v -c ffn.hip -o /tmp/ffn_abl_$v.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC gemm.o gemm_fast.o gemm_wreg.o /tmp/ffn_abl_$v.o outer.o outer_pairs.o tied.o ops.o se3.o favor.o -o ../librfmi_ffnabl$v.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC gemm.o gemm_fast.o gemm_wreg.o conv288.o /tmp/ffn_abl_$v.o outer.o outer_pairs.o tied.o ops.o se3.o favor.o -o ../librfmi_ffnabl$v.so
 done
