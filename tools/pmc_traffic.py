@@ -15,6 +15,9 @@ import sys
 def family(name):
     if name.startswith("void gemm_fast_kernel") or name.startswith("gemm_fast_kernel"):
         return "gemm_fast_kernel"
+    for k in ("conv3x3_c288_kernel", "ffn_fused_kernel", "outer_pairs_kernel"):
+        if k in name:
+            return k
     if "gemm_wreg_kernel" in name:
         return "gemm_wreg_kernel"
     if "tied_logits_split_kernel" in name:
