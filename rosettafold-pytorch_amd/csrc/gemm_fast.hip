@@ -528,6 +528,12 @@ int rf_gemm_fast_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
     else *rc = launch_fast<128, false, false, false, false, true>(p, s);
     return 1;
   }
+#ifdef FAST_STAMP_LN  // timing experiment (tools/gemm_stamps.py LN=1): instrumented twins of the LayerNorm-epilogue kernels
+  if (ln && p.stamps) {
+    *rc = d.N == 288 ? launch_fast<288, true, true, true, true>(p, s) : launch_fast<384, true, true, true, true, false, 128>(p, s);
+    return 1;
+  }
+#endif
   if (ln) {
     *rc = d.N == 288 ? launch_fast<288, true, true, false, true>(p, s) : launch_fast<384, true, true, false, true, false, 128>(p, s);
     return 1;

@@ -269,10 +269,11 @@ class FeedForward(RFModule):
         if pr < R:  # hidden panel stays in the Infinity Cache between the two GEMMs
             xn2, xr2 = xn.view(R, -1), x_res.view(R, -1)
             h = torch.empty(pr, d_ff, device=xn.device, dtype=xn.dtype)
+            nxt, fused = torch.empty(R, xr2.shape[1], device=xn.device, dtype=xn.dtype) if next_ln is not None else None, True
             for r0 in range(0, R, pr):
                 ops.linear(xn2[r0:r0 + pr], w1, b1, act=L.ACT_RELU, out=h)
-                ops.linear(h, w2, b2, out=xr2[r0:r0 + pr], residual=xr2[r0:r0 + pr])
-            return None
+                fused &= ops.linear_residual_ln(h, w2, b2, xr2[r0:r0 + pr], next_ln, nxt[r0:r0 + pr] if nxt is not None else None) is not None
+            return nxt.view(x_res.shape) if nxt is not None and fused else None
         h = ops.linear(xn, w1, b1, act=L.ACT_RELU)
         return ops.linear_residual_ln(h, w2, b2, x_res, next_ln)
 
@@ -694,13 +695,14 @@ class PerformerSelfAttention(RFModule):
                     qkv = torch.empty(pr, W3, device=dev, dtype=T())
                     xn2, xr2 = xn.view(R, D), x_res.view(R, -1)
                     wo, bo = self.wt("o", self.to_out), _f(self.to_out.bias)
+                    nxt, fused = torch.empty(R, xr2.shape[1], device=dev, dtype=T()) if next_ln is not None else None, True
                     for r0 in range(0, R, pr):
                         ops.linear(xn2[r0:r0 + pr], wqkv, None, out=qkv)
                         op = o[r0:r0 + pr]
                         ops.favor_attention(qkv, pcf, op, (RB * W3, so * W3, ss * W3, dh), (RB * inner, so * inner, ss * inner),
                                             0, inner, 2 * inner, nb, Lo, H, Ls, dh, m, not gen, eps)
-                        ops.linear(op, wo, bo, out=xr2[r0:r0 + pr], residual=xr2[r0:r0 + pr])
-                    return None
+                        fused &= ops.linear_residual_ln(op, wo, bo, xr2[r0:r0 + pr], next_ln, nxt[r0:r0 + pr] if nxt is not None else None) is not None
+                    return nxt.view(x_res.shape) if nxt is not None and fused else None
                 qkv = ops.linear(xn, wqkv, None)
                 ops.favor_attention(qkv, pcf, o, (RB * W3, so * W3, ss * W3, dh), (RB * inner, so * inner, ss * inner),
                                     0, inner, 2 * inner, B, Lo, H, Ls, dh, m, not gen, eps)

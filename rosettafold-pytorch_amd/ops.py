@@ -663,16 +663,17 @@ def ffn_fused(xn, w_packed, b1, b2, x_res, next_ln=None):
     return out_ln
 
 
-def linear_residual_ln(x, w, bias, x_res, next_ln):
+def linear_residual_ln(x, w, bias, x_res, next_ln, xn_out=None):
     """x_res += x @ w^T + bias (fp32, in place).  If `next_ln` (an nn.LayerNorm) is given and the fused epilogue applies
-    (bf16 operands, full rows per tile), also returns LayerNorm_next(x_res) in bf16; otherwise returns None and the
-    caller normalises with rf_layernorm."""
+    (bf16 operands, full rows per tile), also returns LayerNorm_next(x_res) in bf16 (written into `xn_out` when given: the
+    row-panel callers pass a slice of one full-size tensor); otherwise returns None and the caller normalises with
+    rf_layernorm."""
     N = w.shape[0]
     rows = x_res.numel() // N
     # whole rows per tile: the persistent GEMM normalises the updated rows in its epilogue (csrc/gemm_fast.hip)
     fused = (FUSE_LN and N in (288, 384) and rows % 256 == 0 and rows >= 16384) or (FUSE_LN_ANY and N <= 384 and N % 4 == 0)
     if fused and next_ln is not None and is_h16(x.dtype) and x_res.is_contiguous() and x.is_contiguous():
-        xn = torch.empty(x_res.shape, device=x_res.device, dtype=x.dtype)
+        xn = torch.empty(x_res.shape, device=x_res.device, dtype=x.dtype) if xn_out is None else xn_out
         linear(x, w, bias, out=x_res, residual=x_res,
                ln=(xn, next_ln.weight.detach(), next_ln.bias.detach(), next_ln.eps))
         return xn

@@ -19,11 +19,20 @@ def main():
     nblk = 65536
     stamps = torch.zeros(nblk, 8, device="cuda", dtype=torch.int64)
     if os.environ.get("FAST"):
+        # LN=1: the residual + next-LayerNorm epilogue variant (needs a library built with -DFAST_STAMP_LN, loaded via RFMI_LIB)
+        if os.environ.get("LN"):
+            res = torch.randn(M, N, device="cuda")
+            xn = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            g, b = torch.ones(N, device="cuda"), torch.zeros(N, device="cuda")
+            bias = torch.zeros(N, device="cuda")
+            run = lambda: ops.linear(x, w, bias, out=res, residual=res, ln=(xn, g, b, 1e-5))
+        else:
+            run = lambda: ops.linear(x, w, None, out=out)
         for _ in range(3):
-            ops.linear(x, w, None, out=out)
+            run()
         torch.cuda.synchronize()
         L.lib.rf_debug_gemm_fast_stamps(stamps.data_ptr())
-        ops.linear(x, w, None, out=out)
+        run()
         torch.cuda.synchronize()
         L.lib.rf_debug_gemm_fast_stamps(None)
         s = stamps.cpu().numpy()
