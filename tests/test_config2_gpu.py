@@ -241,3 +241,23 @@ def test_fused_favor_run_to_run(gen, Ls):
     outs = [f() for _ in range(6)]
     torch.cuda.synchronize()
     assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
+def test_row_panels_bitwise():
+    """RF_MALL_PANEL_MB (opt-in): the feed-forward pair and the q|k|v -> FAVOR+ -> output projection chain run per row panel
+    (whole batch elements for the attention) with the next LayerNorm still in the GEMM epilogue.  Rows are independent in
+    every one of those kernels, so the panelled layer must reproduce the one-launch layer bit for bit."""
+    from rosettafold_pytorch_amd import model as M
+    R.set_compute_dtype(torch.bfloat16)
+    m = build(lambda: R.PairUpdateWithAxialAttentionLayer(DP, 4 * DP, 8, 0.0, {}))
+    x = rn(2, L2, L2, DP).to(DEV)
+    old = M.RT.mall_panel_bytes
+    try:
+        M.RT.mall_panel_bytes = 0
+        ref = m(x.clone())
+        M.RT.mall_panel_bytes = 210 << 20   # q|k|v of one batch element: 201 MB; feed-forward hidden: 302 MB -> two panels
+        assert M.row_panels(2 * L2 * L2, 3 * 512 * 2, L2 * L2) == L2 * L2
+        got = m(x.clone())
+    finally:
+        M.RT.mall_panel_bytes = old
+    assert torch.equal(got, ref)
