@@ -52,7 +52,8 @@ CONFIGS = {
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 FAMILY = {0: "gemm_f32_kernel (fp32 MFMA 16x16x4)", 1: "gemm_bf16_kernel (MFMA 16x16x32)",
           2: "gemm_bf16_kernel<conv3x3> (MFMA 16x16x32)", 3: "gemm_fast_kernel (persistent tiles, MFMA 16x16x32)",
-          4: "gemm_wreg_kernel (register-resident weights, MFMA 16x16x32)"}
+          4: "gemm_wreg_kernel (register-resident weights, MFMA 16x16x32)",
+          5: "ffn_fused_kernel (one-launch feed-forward, MFMA 16x16x32)"}
 
 
 def tree_hash():
@@ -94,12 +95,28 @@ def profile_gemms(run):
         recs.append((s, e, 2.0 * d.M * d.N * d.K * nb, int(fam_of()), d.M, d.N, d.K, nb, nbytes))
         return rc
 
+    # the one-launch feed-forward (rf_ffn_fused, csrc/ffn.hip) is the path's other dense-contraction entry point: family 5.
+    # Algorithmic bytes: input rows + both weight matrices once + fp32 residual read and write + the fused LayerNorm copy.
+    orig_ffn = ops.lib.rf_ffn_fused
+
+    def wrapped_ffn(*a):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = orig_ffn(*a)
+        e.record()
+        M, D, hidden = int(a[14]), int(a[15]), int(a[16])
+        nbytes = M * D * 2 + 2 * D * hidden * 2 + 2 * M * D * 4 + (M * D * 2 if a[9] else 0)
+        recs.append((s, e, 4.0 * M * D * hidden, 5, M, D, hidden, 1, nbytes))
+        return rc
+
     ops.lib.rf_gemm = wrapped
+    ops.lib.rf_ffn_fused = wrapped_ffn
     try:
         run()
         torch.cuda.synchronize()
     finally:
         ops.lib.rf_gemm = orig
+        ops.lib.rf_ffn_fused = orig_ffn
     tab = {}
     for s, e, fl, fam, M, N, K, nb, nbytes in recs:
         t = tab.setdefault((fam, M, N, K, nb), [0.0, 0.0, 0, 0.0])

@@ -633,15 +633,20 @@ def ffn_pack(w1, w2, dtype=None):
     return packed.to(dtype if dtype is not None else h16()).contiguous()
 
 
-# One-launch feed-forward (csrc/ffn.hip): correct, but at the forward's shapes it only ties with the two-GEMM path (402 vs 397 us
-# per MSA block, 511-525 vs 485 us per pair block; DESIGN.md section 5 "fused feed-forward") -- the weight stream of a 128-token
-# tile through L2 -> LDS costs what the hidden round trip through HBM costs -- so it is opt-in (RF_FUSED_FFN=1).
-FUSE_FFN = bool(int(__import__("os").environ.get("RF_FUSED_FFN", "0")))
+# One-launch feed-forward (csrc/ffn.hip).  At the forward's shapes it ties with the two-GEMM path on time (402 vs 397-417 us per MSA
+# block, 511-525 vs 485-518 us per pair block; 315.8-317.0 vs 316.6-317.4 ms per forward on the same box) -- the weight stream of a
+# 128-token tile through L2 -> LDS costs what the hidden round trip through HBM costs -- but it takes 0.15 TB of HBM traffic out of
+# every forward (the hidden activations never exist in memory), so it is the default; RF_FUSED_FFN=0 restores the two GEMMs
+# (DESIGN.md section 5 "fused feed-forward").
+# RF_FUSED_FFN: 1 (default: both widths) | 0 (off) | 384 | 288 (only the feed-forward blocks of that model width)
+_ffn_env = __import__("os").environ.get("RF_FUSED_FFN", "1").strip()
+FUSE_FFN = _ffn_env not in ("", "0")
+FUSE_FFN_WIDTHS = (int(_ffn_env),) if _ffn_env in ("288", "384") else (288, 384)
 
 
 def ffn_fused_applies(xn, x_res, D, hidden):
     rows = x_res.numel() // D
-    return (FUSE_FFN and is_h16(xn.dtype) and D in (288, 384) and hidden % 32 == 0 and rows % 128 == 0 and rows >= 16384
+    return (FUSE_FFN and is_h16(xn.dtype) and D in FUSE_FFN_WIDTHS and hidden % 32 == 0 and rows % 128 == 0 and rows >= 16384
             and x_res.is_contiguous() and xn.is_contiguous() and x_res.dtype == F32
             and 288 <= hidden and hidden * 4 <= 160 * 1024 - 153 * 1024)
 

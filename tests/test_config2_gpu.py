@@ -247,17 +247,18 @@ def test_row_panels_bitwise():
     """RF_MALL_PANEL_MB (opt-in): the feed-forward pair and the q|k|v -> FAVOR+ -> output projection chain run per row panel
     (whole batch elements for the attention) with the next LayerNorm still in the GEMM epilogue.  Rows are independent in
     every one of those kernels, so the panelled layer must reproduce the one-launch layer bit for bit."""
-    from rosettafold_pytorch_amd import model as M
+    from rosettafold_pytorch_amd import model as M, ops
     R.set_compute_dtype(torch.bfloat16)
     m = build(lambda: R.PairUpdateWithAxialAttentionLayer(DP, 4 * DP, 8, 0.0, {}))
     x = rn(2, L2, L2, DP).to(DEV)
-    old = M.RT.mall_panel_bytes
+    old, old_ffn = M.RT.mall_panel_bytes, ops.FUSE_FFN
     try:
+        ops.FUSE_FFN = False   # the two-GEMM feed-forward is the one that has a panel form
         M.RT.mall_panel_bytes = 0
         ref = m(x.clone())
         M.RT.mall_panel_bytes = 210 << 20   # q|k|v of one batch element: 201 MB; feed-forward hidden: 302 MB -> two panels
         assert M.row_panels(2 * L2 * L2, 3 * 512 * 2, L2 * L2) == L2 * L2
         got = m(x.clone())
     finally:
-        M.RT.mall_panel_bytes = old
+        M.RT.mall_panel_bytes, ops.FUSE_FFN = old, old_ffn
     assert torch.equal(got, ref)
