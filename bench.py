@@ -51,7 +51,7 @@ CONFIGS = {
 }
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 FAMILY = {0: "gemm_f32_kernel (fp32 MFMA 16x16x4)", 1: "gemm_bf16_kernel (MFMA 16x16x32)",
-          2: "gemm_bf16_kernel<conv3x3> (MFMA 16x16x32)", 3: "gemm_fast_kernel (persistent tiles, MFMA 16x16x32)",
+          2: "conv3x3_c288_kernel (3x3 convolution: halo-tile kernel; other channel counts take the implicit-GEMM tile kernel)", 3: "gemm_fast_kernel (persistent tiles, MFMA 16x16x32)",
           4: "gemm_wreg_kernel (register-resident weights, MFMA 16x16x32)",
           5: "ffn_fused_kernel (one-launch feed-forward, MFMA 16x16x32)"}
 
