@@ -43,7 +43,7 @@ class _Runtime:
     fused_outer = not bool(int(__import__("os").environ.get("RF_NO_FUSED_OUTER", "0")))  # outer product -> LN -> Linear in one kernel
     tied_v2 = not bool(int(__import__("os").environ.get("RF_TIED_V1", "0")))  # head-major q|k|v + collapsed weights + A.V kernel
     tied_fold_w = not bool(int(__import__("os").environ.get("RF_TIED_NO_FOLD", "0")))  # position weights folded into q by the projection's epilogue
-    head_major_qkv = bool(int(__import__("os").environ.get("RF_HEAD_MAJOR_QKV", "0")))
+    head_major_qkv = int(__import__("os").environ.get("RF_HEAD_MAJOR_QKV", "0"))  # 1: every FAVOR+ layer, 2: only where the sequence is the inner row index
     # Producer -> consumer chains whose intermediate (q|k|v, feed-forward hidden) is larger than this many bytes are run
     # panel by panel, so the intermediate panel is still in the 256 MB Infinity Cache when its consumer reads it
     # (tools/mall_chunk_bench.py: projection + FAVOR alone 958 -> 842 us at 200 MB panels; inside the full forward the
@@ -671,7 +671,7 @@ class PerformerSelfAttention(RFModule):
             pcf = pc if gen else self.proj_scaled(log2e=True)
             eps = 1e-3 if gen else 1e-4
             wqkv = self.wcat("qkv", [self.to_q, self.to_k, self.to_v])
-            if RT.head_major_qkv:
+            if RT.head_major_qkv == 1 or (RT.head_major_qkv == 2 and axis == 2):
                 # q|k|v written head-major [B, Lo, 3, H, Ls, 64] straight from the projection GEMM's epilogue: every
                 # (b, o, head) tile the FAVOR kernel DMAs is then one contiguous 8 KB x (Ls/64) block
                 qkv = torch.empty(B, Lo, 3, H, Ls, dh, device=dev, dtype=T())
