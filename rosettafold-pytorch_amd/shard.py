@@ -18,9 +18,25 @@ def shard_range(n_items, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def pack_results(logits, xyz, plddt):
-    return torch.cat([logits[k].reshape(-1).float() for k in LOGIT_KEYS] + [xyz.reshape(-1).float(),
-                                                                           plddt.reshape(-1).float()])
+def pack_results(logits, xyz, plddt, numel=None):
+    """One flat fp32 buffer (logits | xyz | plddt), zero-padded to `numel` elements.  Device tensors are packed by the
+    library's own copy kernel (rf_axpby: one launch per piece on the forward's stream, no ATen kernel in the timed region);
+    host tensors (the gloo tests) by torch.cat."""
+    pieces = [logits[k] for k in LOGIT_KEYS] + [xyz, plddt]
+    n = sum(t.numel() for t in pieces)
+    total = n if numel is None else max(n, numel)
+    if n > 0 and all(t.is_cuda and t.dtype == torch.float32 for t in pieces):
+        from . import ops
+        flat = torch.empty(total, device=pieces[0].device, dtype=torch.float32)
+        o = 0
+        for t in pieces:
+            ops.axpby(t.contiguous(), 1.0, None, 0.0, flat[o:o + t.numel()])
+            o += t.numel()
+        if total > n:
+            ops.fill(flat[n:], 0.0)
+        return flat
+    flat = torch.cat([t.reshape(-1).float() for t in pieces])
+    return flat if total == n else torch.cat([flat, flat.new_zeros(total - n)])
 
 
 def unpack_results(flat, B, L):
@@ -50,10 +66,7 @@ def gather_results(logits, xyz, plddt, dst=0, batch_sizes=None):
         batch_sizes = [B] * world
     if len(batch_sizes) != world or batch_sizes[rank] != B:
         raise ValueError(f"batch_sizes {batch_sizes} does not describe this rank (rank {rank} holds {B})")
-    flat = pack_results(logits, xyz, plddt)
-    nmax = result_numel(max(batch_sizes), L)
-    if flat.numel() < nmax:
-        flat = torch.cat([flat, flat.new_zeros(nmax - flat.numel())])
+    flat = pack_results(logits, xyz, plddt, result_numel(max(batch_sizes), L))
     if dist.get_backend() == "gloo" and flat.is_cuda:
         flat = flat.cpu()  # gloo has no device gather; RCCL ("nccl") gathers in HBM
     bufs = [torch.empty_like(flat) for _ in range(world)] if rank == dst else None
