@@ -51,7 +51,9 @@ class GraphedForward:
                 side.synchronize()
                 self.graph = torch.cuda.CUDAGraph()
                 S._PENDING_EDGE_COUNTS.clear()
-                with torch.cuda.graph(self.graph, stream=side):
+                # thread-local capture mode: HIP calls of OTHER threads (the RCCL watchdog of a torch.distributed process group
+                # polling its events) must not invalidate this thread's capture
+                with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
                     self._out = self.model.forward_validated(*self._in, self._mono)
                 self._edge_counts = list(S._PENDING_EDGE_COUNTS)   # static tensors of the graph: checked after every replay
                 S._PENDING_EDGE_COUNTS.clear()
