@@ -647,10 +647,13 @@ class PerformerSelfAttention(RFModule):
             return pp.to(T()).contiguous()
         return self.cached(("proj", log2e), make)
 
-    def attend(self, xn, x_res, axis, next_ln=None):
+    def attend(self, xn, x_res, axis, next_ln=None, seq_group=None):
         """xn: T [B,L1,L2,D] layer-normed input; sequences run along `axis` (1 or 2); x_res (fp32, same shape)
         += to_out(linear attention).  All intermediates are addressed by strides: no transposes.
-        Returns next_ln(x_res) when the fused residual+LayerNorm epilogue applies, else None."""
+        Returns next_ln(x_res) when the fused residual+LayerNorm epilogue applies, else None.
+        seq_group: a torch.distributed group over which the SEQUENCE axis is sharded (every rank holds a slice of every
+        sequence: pair-track row blocks).  Linear attention communicates contexts, not maps: the local
+        k'^T [v | 1] sums are all-reduced (fp32) before the queries are applied (rf.py:505-518 semantics unchanged)."""
         B, L1, L2, D = xn.shape
         H, dh, inner = self.heads, self.dim_head, self.inner
         dev = xn.device
@@ -663,7 +666,10 @@ class PerformerSelfAttention(RFModule):
         m = self.fast_attention.projection_matrix.shape[0]
         pc = self.proj_scaled()
         gen = self.generalized
-        if RT.fused_favor and ops.is_h16(T()) and dh == 64 and m == M_FEAT and (
+        if seq_group is not None and not gen:
+            raise NotImplementedError("sequence-sharded attention is built for the generalized (ReLU) feature map of the pair "
+                                      "track only: the softmax feature map needs the global key maximum first")
+        if seq_group is None and RT.fused_favor and ops.is_h16(T()) and dh == 64 and m == M_FEAT and (
                 Ls in (64, 128, 256) or (gen and Ls > 256 and Ls % 256 == 0)):
             # fused path: one projection GEMM (q|k|v) + one persistent kernel; q', k', ctx never leave the chip
             W3 = 3 * inner
@@ -732,9 +738,14 @@ class PerformerSelfAttention(RFModule):
                  b_bs=(RB * D, so * D, 0), b_row=(0, 0, ss * D),
                  c_bs=(Lo * H * VT_ROWS * Ls, H * VT_ROWS * Ls, 0), c_row=(dh, VT_ROWS * Ls, Ls))
         # context^T [S,80,M_PAD] = v^T k'
-        ctx = torch.empty(S, VT_ROWS, M_PAD, device=dev, dtype=T())
+        ctx = torch.empty(S, VT_ROWS, M_PAD, device=dev, dtype=T() if seq_group is None else F32)
         ops.gemm(vt, kt, ctx, VT_ROWS, M_PAD, Ls, batch=(S, 1, 1), a_bs=(VT_ROWS * Ls, 0, 0),
                  b_bs=(M_PAD * Ls, 0, 0), c_bs=(VT_ROWS * M_PAD, 0, 0))
+        if seq_group is not None:
+            # the one exchange of a sequence-sharded layer: [B * Lo * H, 80, 288] fp32 partial contexts (+ k' sums in row 64)
+            from . import shard
+            shard.all_reduce_sum(ctx, seq_group)
+            ctx = ops.cast(ctx, T())
         # numerator | denominator: num[b,p1,p2,h,0:64 | 64]
         num = torch.empty(R * H, VT_ROWS, device=dev, dtype=F32)
         ops.gemm(dq, ctx, num, Ls, VT_ROWS, M_PAD, batch=(B, Lo, H),
@@ -1005,12 +1016,15 @@ class PairUpdateWithAxialAttentionLayer(RFModule):
             Residual(nn.Sequential(LayerNorm(d_pair), self.ff)),
         )
 
-    def run(self, x, xn=None, next_ln=None):
-        """x fp32 in place; xn = layer[0] pre-norm of x if already produced; returns next_ln(x) or None."""
+    def run(self, x, xn=None, next_ln=None, row_group=None):
+        """x fp32 in place; xn = layer[0] pre-norm of x if already produced; returns next_ln(x) or None.
+        row_group: x holds a block of ROWS (dim 1) of the pair tensor, the other row blocks live on the other ranks of this
+        torch.distributed group (shard.pair_axial_layer_row_sharded): the RowWise attention all-reduces its contexts, the
+        ColWise attention and the feed-forward are local."""
         l0, l1, l2 = self.layer[0].fn[0], self.layer[1].fn[0], self.layer[2].fn[0]
         if xn is None:
             xn = ln(l0, x)
-        xn = self.row_attn.attend(xn, x, axis=1, next_ln=l1)
+        xn = self.row_attn.attend(xn, x, axis=1, next_ln=l1, seq_group=row_group)
         if xn is None:
             xn = ln(l1, x)
         xn = self.col_attn.attend(xn, x, axis=2, next_ln=l2)
@@ -1263,14 +1277,25 @@ class ResBlock2D(RFModule):
             nn.Conv2d(channel, channel, kernel_size, dilation=dilation, padding="same", bias=False),
             nn.InstanceNorm2d(channel, affine=True, eps=1e-6)))
 
-    def run(self, x_t, x_f):
-        """x_t: T NHWC (conv input), x_f: fp32 copy (residual).  Returns (T, fp32) of elu(block(x)+x)."""
+    def run(self, x_t, x_f, row_group=None, rows_global=None):
+        """x_t: T NHWC (conv input), x_f: fp32 copy (residual).  Returns (T, fp32) of elu(block(x)+x).
+        row_group / rows_global: x holds a block of the picture's rows (shard.resblock_row_sharded): every convolution first
+        fetches `dilation` rows from each neighbouring rank, the InstanceNorm sums are all-reduced."""
         f = self.layer.fn
-        y = conv3x3(self, "c1", f[0], x_t, self.dilation)
-        y, _ = ops.instnorm(y, _f(f[1].weight), _f(f[1].bias), eps=f[1].eps, act=L.ACT_ELU, out_dtype=T())
-        y = conv3x3(self, "c2", f[4], y, self.dilation)
+        kw = {} if row_group is None else {"row_group": row_group, "rows_global": rows_global}
+
+        def conv(key, c, x):
+            if row_group is None:
+                return conv3x3(self, key, c, x, self.dilation)
+            from . import shard
+            xh = shard.exchange_row_halos(x, self.dilation, row_group)
+            return shard.drop_row_halos(conv3x3(self, key, c, xh, self.dilation), self.dilation)
+
+        y = conv("c1", f[0], x_t)
+        y, _ = ops.instnorm(y, _f(f[1].weight), _f(f[1].bias), eps=f[1].eps, act=L.ACT_ELU, out_dtype=T(), **kw)
+        y = conv("c2", f[4], y)
         o_f, o_t = ops.instnorm(y, _f(f[5].weight), _f(f[5].bias), eps=f[5].eps, residual=x_f, act=L.ACT_ELU,
-                                out_dtype=F32, out2_dtype=T())
+                                out_dtype=F32, out2_dtype=T(), **kw)
         return o_t, o_f
 
     def forward(self, x):  # NCHW like the reference

@@ -345,8 +345,11 @@ def weighted_msa_sum(x, w, y, y_ld):
           "rf_weighted_msa_sum")
 
 
-def instnorm(x, gamma, beta, *, eps=1e-6, residual=None, act=L.ACT_NONE, out_dtype=None, out2_dtype=None):
-    """InstanceNorm2d(affine) over NHWC x [B,H,W,C]; returns (y, y2) where y2 is an optional second copy."""
+def instnorm(x, gamma, beta, *, eps=1e-6, residual=None, act=L.ACT_NONE, out_dtype=None, out2_dtype=None, row_group=None,
+             rows_global=None):
+    """InstanceNorm2d(affine) over NHWC x [B,H,W,C]; returns (y, y2) where y2 is an optional second copy.
+    row_group / rows_global: x is a block of H of the picture's rows_global rows, the other blocks live on the other ranks of
+    the torch.distributed group: the per-(b, c) sums are all-reduced (2*B*C doubles) before they are applied."""
     B, H, W, Cc = x.shape
     _need_cuda(x, gamma, beta, residual)
     sums = torch.empty(B * Cc * 2, device=x.device, dtype=torch.float64)  # fully written by the ordered finalize step
@@ -354,6 +357,11 @@ def instnorm(x, gamma, beta, *, eps=1e-6, residual=None, act=L.ACT_NONE, out_dty
     ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
     check(lib.rf_instnorm_stats(ptr(x), dcode(x.dtype), ptr(sums), B, H * W, Cc, ptr(ws), ws_bytes, stream()),
           "rf_instnorm_stats")
+    if row_group is not None:
+        from . import shard
+        shard.all_reduce_sum(sums, row_group)
+        # rf_instnorm_apply divides by ITS pixel count: hand it global sums scaled to the local block (exact up to one rounding)
+        sums.mul_(float(H) / float(rows_global))
     y = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
     y2 = torch.empty(x.shape, device=x.device, dtype=out2_dtype) if out2_dtype is not None else None
     check(lib.rf_instnorm_apply(ptr(x), dcode(x.dtype), ptr(sums), ptr(gamma), ptr(beta), eps, ptr(residual), act,

@@ -99,3 +99,92 @@ def forward_sharded(model, msa, seq, aa_idx, dst=0):
         return None
     out = {k: torch.cat([p[0][k] for p in parts]) for k in LOGIT_KEYS}
     return out, torch.cat([p[1] for p in parts]), torch.cat([p[2] for p in parts])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Pair-track row-block sharding, first piece: one axial-attention layer on a block of rows
+# ----------------------------------------------------------------------------------------------------------------------
+def all_reduce_sum(t, group=None):
+    """In-place sum over the ranks of `group` (RCCL on device tensors; the gloo rehearsal goes through the host)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+def pair_axial_layer_row_sharded(layer, x_rows, group=None):
+    """PairUpdateWithAxialAttentionLayer (rf.py:501-528) on the row block x_rows = pair[:, r0:r1] held by this rank; the
+    ranks of `group` (default: all) hold the other row blocks, in any split.  The attention along the rows' index (RowWise,
+    rf.py:31-41: sequences over i for fixed j) spans the ranks: its Performer contexts k'^T [v | 1] -- [B * L * heads, 80, 288]
+    fp32 per layer, independent of the block height -- are summed with one all-reduce; everything else is local.  Returns
+    the updated row block (fp32)."""
+    from . import model as M
+    g = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
+    x = M.fresh_f32(x_rows)
+    layer.run(x, row_group=g)
+    return x
+
+
+def _peer(group, r):
+    return r if group is None or group is dist.group.WORLD else dist.get_global_rank(group, r)
+
+
+def exchange_row_halos(x, d, group=None):
+    """x: [B, h, W, C] contiguous block of picture rows on this rank (the ranks of `group` hold consecutive blocks in rank
+    order).  Returns [B, h + 2 d, W, C]: the block with d rows of each neighbour attached (zeros beyond the picture: the 'same'
+    padding of the dilated 3x3 convolutions, resnet.py:19-38).  One send + one receive per neighbour (RCCL point-to-point on
+    device buffers; the gloo rehearsal stages through the host); slicing and placement by rf_copy4d."""
+    from . import ops
+    B, h, W, Cc = x.shape
+    if h < d:
+        raise ValueError(f"row block of {h} rows is lower than the halo of {d}: halos would span more than one neighbour")
+    n = dist.get_world_size(group) if dist.is_initialized() else 1
+    r = dist.get_rank(group) if dist.is_initialized() else 0
+    row = W * Cc
+    xh = ops.zeros(B, h + 2 * d, W, Cc, device=x.device, dtype=x.dtype)
+    ops.copy4d(x, (h * row, row, Cc, 1), xh, ((h + 2 * d) * row, row, Cc, 1), (B, h, W, Cc), y_off=d * row)
+    if n == 1:
+        return xh
+    host = dist.get_backend(group) == "gloo"
+    cut = lambda off: ops.copy4d(x, (h * row, row, Cc, 1), torch.empty(B, d, W, Cc, device=x.device, dtype=x.dtype),  # noqa: E731
+                                 (d * row, row, Cc, 1), (B, d, W, Cc), x_off=off)
+    ops_, recv = [], {}
+    for peer, send_off, place_off in ((r - 1, 0, 0), (r + 1, (h - d) * row, (d + h) * row)):
+        if 0 <= peer < n:
+            out = cut(send_off)
+            buf = torch.empty(B, d, W, Cc, device="cpu" if host else x.device, dtype=x.dtype)
+            ops_.append(dist.P2POp(dist.isend, out.cpu() if host else out, _peer(group, peer), group))
+            ops_.append(dist.P2POp(dist.irecv, buf, _peer(group, peer), group))
+            recv[place_off] = buf
+    if not host:
+        torch.cuda.current_stream().synchronize()  # the send buffers are complete before RCCL's stream reads them
+    for w in dist.batch_isend_irecv(ops_):
+        w.wait()
+    for place_off, buf in recv.items():
+        ops.copy4d(buf.to(x.device), (d * row, row, Cc, 1), xh, ((h + 2 * d) * row, row, Cc, 1), (B, d, W, Cc), y_off=place_off)
+    return xh
+
+
+def drop_row_halos(y, d):
+    """[B, h + 2 d, W, C] -> the contiguous inner [B, h, W, C]."""
+    from . import ops
+    B, hh, W, Cc = y.shape
+    h, row = hh - 2 * d, W * Cc
+    out = torch.empty(B, h, W, Cc, device=y.device, dtype=y.dtype)
+    return ops.copy4d(y, (hh * row, row, Cc, 1), out, (h * row, row, Cc, 1), (B, h, W, Cc), x_off=d * row)
+
+
+def resblock_row_sharded(block, x_rows, rows_global, group=None):
+    """ResBlock2D (resnet.py:15-44) on the block of picture rows x_rows = x[:, r0:r1] (NHWC, fp32) held by this rank: two dilated
+    3x3 convolutions (halo rows from the neighbouring ranks), two InstanceNorms (all-reduced sums), residual, ELU.  Returns the
+    updated row block (fp32)."""
+    from . import model as M, ops
+    g = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
+    xf = M.fresh_f32(x_rows)
+    return block.run(ops.cast(xf, M.T()), xf, row_group=g, rows_global=rows_global)[1]
+

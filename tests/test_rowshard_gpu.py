@@ -1,0 +1,137 @@
+"""Pair-track row-block sharding, first piece (reference semantics rf.py:501-528): one
+PairUpdateWithAxialAttentionLayer on two row blocks of unequal height held by two ranks (both on cuda:0, gloo rendezvous --
+RCCL needs one GPU per rank).  The RowWise attention spans the ranks and all-reduces its Performer contexts; the stacked row
+blocks must equal the single-process layer on the whole tensor (fp32 mode: the same kernels, only the context partial sums are
+added in another order; 16-bit modes: within the layer tolerance of tests/test_config2_gpu.py)."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+D, H, L1, L2 = 96, 4, 48, 40
+CUT = 32  # rank 0: rows [0, 32), rank 1: rows [32, 48)
+
+
+def _x():
+    return torch.randn(1, L1, L2, D, generator=torch.Generator().manual_seed(5))
+
+
+def _worker(rank, world, port, wpath, opath, dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rosettafold_pytorch_amd as R
+    from rosettafold_pytorch_amd import shard
+    R.set_compute_dtype(dtype)
+    layer = R.PairUpdateWithAxialAttentionLayer(D, 2 * D, H, 0.0, {})
+    layer.load_state_dict(torch.load(wpath))
+    layer = layer.to("cuda:0")
+    lo, hi = (0, CUT) if rank == 0 else (CUT, L1)
+    out = shard.pair_axial_layer_row_sharded(layer, _x()[:, lo:hi].to("cuda:0"))
+    torch.cuda.synchronize()
+    torch.save(out.cpu(), f"{opath}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)],
+                         ids=["fp32", "bf16", "fp16"])
+def test_axial_layer_row_sharded_world2(tmp_path, dtype, tol):
+    import rosettafold_pytorch_amd as R
+    wpath, opath = str(tmp_path / "layer.pt"), str(tmp_path / "rows.pt")
+    torch.manual_seed(77)
+    layer = R.PairUpdateWithAxialAttentionLayer(D, 2 * D, H, 0.0, {})
+    torch.save(layer.state_dict(), wpath)
+    ctx = mp.get_context("spawn")
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, wpath, opath, dtype)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    got = torch.cat([torch.load(f"{opath}.{r}") for r in range(2)], 1)
+    R.set_compute_dtype(dtype)
+    try:
+        ref = layer.to("cuda:0")(_x().to("cuda:0")).cpu()
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    # ... and against the CPU oracle's restatement of the reference layer on the whole tensor
+    from oracle import rf_oracle as O
+    st = {"m." + k: v.detach().float().cpu() for k, v in layer.state_dict().items()}
+    ora = O.pair_axial_layer(st, "m", _x(), H)
+    err_o = ((got - ora).abs().max() / ora.abs().max()).item()
+    print(f"\n[row shard {dtype}] two row blocks (32 + 16 of 48): vs one process max-rel {err:.3e}, vs oracle {err_o:.3e}")
+    assert got.shape == ref.shape and err < tol and err_o < tol, (err, err_o)
+
+
+# ---- ResBlock2D on row blocks: halo rows from the neighbours, all-reduced InstanceNorm sums -----------------------------
+CH, DIL, PH, PW = 64, 4, 40, 24   # picture rows split 24 + 16 (both >= the halo of 4)
+PCUT = 24
+
+
+def _pic():
+    return torch.randn(1, PH, PW, CH, generator=torch.Generator().manual_seed(9))  # NHWC
+
+
+def _res_worker(rank, world, port, wpath, opath, dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rosettafold_pytorch_amd as R
+    from rosettafold_pytorch_amd import shard
+    R.set_compute_dtype(dtype)
+    blk = R.ResBlock2D(CH, 3, DIL, 0.0)
+    blk.load_state_dict(torch.load(wpath))
+    blk = blk.to("cuda:0")
+    lo, hi = (0, PCUT) if rank == 0 else (PCUT, PH)
+    out = shard.resblock_row_sharded(blk, _pic()[:, lo:hi].to("cuda:0"), PH)
+    torch.cuda.synchronize()
+    torch.save(out.cpu(), f"{opath}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)],
+                         ids=["fp32", "bf16", "fp16"])
+def test_resblock_row_sharded_world2(tmp_path, dtype, tol):
+    import rosettafold_pytorch_amd as R
+    from rosettafold_pytorch_amd import ops
+    wpath, opath = str(tmp_path / "blk.pt"), str(tmp_path / "rows.pt")
+    torch.manual_seed(78)
+    blk = R.ResBlock2D(CH, 3, DIL, 0.0)
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.InstanceNorm2d):
+                m.weight.normal_(1.0, 0.2)
+                m.bias.normal_(0.0, 0.2)
+    torch.save(blk.state_dict(), wpath)
+    ctx = mp.get_context("spawn")
+    port = 37500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_res_worker, args=(r, 2, port, wpath, opath, dtype)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    got = torch.cat([torch.load(f"{opath}.{r}") for r in range(2)], 1)
+    R.set_compute_dtype(dtype)
+    try:
+        x = _pic().to("cuda:0")
+        ref = blk.to("cuda:0").run(ops.cast(x, R.model.T()), x)[1].cpu()
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    from oracle import rf_oracle as O
+    st = {"m." + k: v.detach().float().cpu() for k, v in blk.state_dict().items()}
+    ora = O.resblock2d(st, "m", _pic().permute(0, 3, 1, 2), DIL).permute(0, 2, 3, 1)
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    err_o = ((got - ora).abs().max() / ora.abs().max()).item()
+    print(f"\n[row shard resblock {dtype}] rows 24 + 16 of 40, dilation {DIL}: vs one process max-rel {err:.3e}, vs oracle {err_o:.3e}")
+    assert got.shape == ref.shape and err < tol and err_o < tol, (err, err_o)
