@@ -1318,13 +1318,14 @@ class ResNet(RFModule):
         self.layer = nn.Sequential(*layers)
         self.n_res_blocks = n_res_blocks
 
-    def run(self, x_t):
-        """x_t: T NHWC -> fp32 NHWC logits."""
+    def run(self, x_t, row_group=None, rows_global=None):
+        """x_t: T NHWC -> fp32 NHWC logits.  row_group / rows_global: x_t is a block of the picture's rows (see ResBlock2D.run)."""
         l0, l1 = self.layer[0], self.layer[1]
+        kw = {} if row_group is None else {"row_group": row_group, "rows_global": rows_global}
         h = ops.linear(x_t, self.wt("in", l0), None)
-        h_f, h_t = ops.instnorm(h, _f(l1.weight), _f(l1.bias), eps=l1.eps, act=L.ACT_ELU, out_dtype=F32, out2_dtype=T())
+        h_f, h_t = ops.instnorm(h, _f(l1.weight), _f(l1.bias), eps=l1.eps, act=L.ACT_ELU, out_dtype=F32, out2_dtype=T(), **kw)
         for b in range(self.n_res_blocks):
-            h_t, h_f = self.layer[3 + b].run(h_t, h_f)
+            h_t, h_f = self.layer[3 + b].run(h_t, h_f, **kw)
         lo = self.layer[3 + self.n_res_blocks]
         return ops.linear(h_t, self.wt("out", lo), _f(lo.bias), out_dtype=F32)
 
@@ -1348,12 +1349,22 @@ class PredictionHead(RFModule):
     def forward(self, pair):
         return self.run(pair.float().contiguous())
 
-    def run(self, pair):
-        B, Lr, _, Cc = pair.shape
+    def run(self, pair, row_group=None):
+        """pair fp32 [B, L, L, C] -> the four logit maps (fp32 NHWC).  row_group: `pair` is this rank's block of rows
+        [B, h, L, C] (contiguous split shard.shard_range(L, world, rank)); the symmetrisation (rf.py:1160) fetches the
+        transposed sub-blocks from the other ranks, the ResNets exchange halo rows and InstanceNorm sums; returns the same rows
+        of the logit maps."""
+        B, h, Lr, Cc = pair.shape
         x = ops.linear(ln(self.proj[0], pair), self.wt("p", self.proj[1]), _f(self.proj[1].bias), out_dtype=F32)
-        xt = torch.empty_like(x)
-        ops.copy4d(x, (Lr * Lr * Cc, Cc, Lr * Cc, 1), xt, (Lr * Lr * Cc, Lr * Cc, Cc, 1), (B, Lr, Lr, Cc))
+        if row_group is None:
+            xt = torch.empty_like(x)
+            ops.copy4d(x, (Lr * Lr * Cc, Cc, Lr * Cc, 1), xt, (Lr * Lr * Cc, Lr * Cc, Cc, 1), (B, Lr, Lr, Cc))
+            kw = {}
+        else:
+            from . import shard
+            xt = shard.transpose_row_sharded(x, row_group)
+            kw = {"row_group": row_group, "rows_global": Lr}
         xs = ops.axpby(x, 0.5, xt, 0.5, torch.empty(x.shape, device=x.device, dtype=T()))
         x_t = ops.cast(x, T())
-        return {"theta": self.theta_head[0].run(x_t), "phi": self.phi_head[0].run(x_t),
-                "dist": self.dist_head[0].run(xs), "omega": self.omega_head[0].run(xs)}
+        return {"theta": self.theta_head[0].run(x_t, **kw), "phi": self.phi_head[0].run(x_t, **kw),
+                "dist": self.dist_head[0].run(xs, **kw), "omega": self.omega_head[0].run(xs, **kw)}

@@ -188,3 +188,53 @@ def resblock_row_sharded(block, x_rows, rows_global, group=None):
     xf = M.fresh_f32(x_rows)
     return block.run(ops.cast(xf, M.T()), xf, row_group=g, rows_global=rows_global)[1]
 
+
+def transpose_row_sharded(x_rows, group=None):
+    """x_rows: fp32 / 16-bit [B, h, L, C] = rows shard_range(L, world, rank) of a square [B, L, L, C] tensor.  Returns the same
+    rows of its transpose: out[b, i, j] = x[b, j, i].  Rank r needs, from every rank s, the sub-block x[s rows, r columns]: one
+    send + one receive per pair of ranks (the diagonal block stays local); the transposition happens in the placing rf_copy4d."""
+    from . import ops
+    B, h, Lr, Cc = x_rows.shape
+    n = dist.get_world_size(group) if dist.is_initialized() else 1
+    r = dist.get_rank(group) if dist.is_initialized() else 0
+    r0, r1 = shard_range(Lr, n, r)
+    if r1 - r0 != h:
+        raise ValueError(f"rank {r} holds {h} rows; the contiguous split of {Lr} rows over {n} ranks gives it {r1 - r0}")
+    out = torch.empty_like(x_rows)
+    row = Lr * Cc
+    host = n > 1 and dist.get_backend(group) == "gloo"
+    ops_, recv = [], {}
+    for s_ in range(n):
+        s0, s1 = shard_range(Lr, n, s_)
+        hs = s1 - s0
+        if hs == 0 or h == 0:
+            continue
+        # my rows, columns of rank s: [B, h, hs, C] contiguous
+        blk = ops.copy4d(x_rows, (h * row, row, Cc, 1), torch.empty(B, h, hs, Cc, device=x_rows.device, dtype=x_rows.dtype),
+                         (h * hs * Cc, hs * Cc, Cc, 1), (B, h, hs, Cc), x_off=s0 * Cc)
+        if s_ == r:
+            recv[s_] = blk
+            continue
+        buf = torch.empty(B, hs, h, Cc, device="cpu" if host else x_rows.device, dtype=x_rows.dtype)  # rank s's rows, my columns
+        ops_.append(dist.P2POp(dist.isend, blk.cpu() if host else blk, _peer(group, s_), group))
+        ops_.append(dist.P2POp(dist.irecv, buf, _peer(group, s_), group))
+        recv[s_] = buf
+    if ops_:
+        if not host:
+            torch.cuda.current_stream().synchronize()
+        for w in dist.batch_isend_irecv(ops_):
+            w.wait()
+    for s_, buf in recv.items():
+        s0, s1 = shard_range(Lr, n, s_)
+        hs = s1 - s0
+        # buf[b, j - s0, i - r0, c] -> out[b, i - r0, j, c]
+        ops.copy4d(buf.to(x_rows.device), (hs * h * Cc, Cc, h * Cc, 1), out, (h * row, row, Cc, 1), (B, h, hs, Cc), y_off=s0 * Cc)
+    return out
+
+
+def prediction_head_row_sharded(head, pair_rows, group=None):
+    """PredictionHead (rf.py:1130-1172) on this rank's rows shard_range(L, world, rank) of the pair tensor: returns the same
+    rows of the four logit maps (fp32 NHWC dict)."""
+    g = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
+    return head.run(pair_rows.float().contiguous(), row_group=g)
+

@@ -135,3 +135,66 @@ def test_resblock_row_sharded_world2(tmp_path, dtype, tol):
     err_o = ((got - ora).abs().max() / ora.abs().max()).item()
     print(f"\n[row shard resblock {dtype}] rows 24 + 16 of 40, dilation {DIL}: vs one process max-rel {err:.3e}, vs oracle {err_o:.3e}")
     assert got.shape == ref.shape and err < tol and err_o < tol, (err, err_o)
+
+
+# ---- PredictionHead on row blocks: transposed sub-blocks for the symmetrisation + four row-sharded ResNets -----------------
+HC, HL, HNB = 64, 42, 3   # 42 rows over 2 ranks (21 + 21), three residual blocks (dilations 1, 2, 4)
+
+
+def _pair():
+    return torch.randn(1, HL, HL, HC, generator=torch.Generator().manual_seed(13))
+
+
+def _head_worker(rank, world, port, wpath, opath, dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rosettafold_pytorch_amd as R
+    from rosettafold_pytorch_amd import shard
+    R.set_compute_dtype(dtype)
+    head = R.PredictionHead(HC, HNB, 0.0)
+    head.load_state_dict(torch.load(wpath))
+    head = head.to("cuda:0")
+    lo, hi = shard.shard_range(HL, world, rank)
+    out = shard.prediction_head_row_sharded(head, _pair()[:, lo:hi].to("cuda:0"))
+    torch.cuda.synchronize()
+    torch.save({k: v.cpu() for k, v in out.items()}, f"{opath}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 5e-5), (torch.float16, 1e-2)], ids=["fp32", "fp16"])
+def test_prediction_head_row_sharded_world2(tmp_path, dtype, tol):
+    import rosettafold_pytorch_amd as R
+    wpath, opath = str(tmp_path / "head.pt"), str(tmp_path / "rows.pt")
+    torch.manual_seed(79)
+    head = R.PredictionHead(HC, HNB, 0.0)
+    with torch.no_grad():
+        for m in head.modules():
+            if isinstance(m, torch.nn.InstanceNorm2d):
+                m.weight.normal_(1.0, 0.2)
+                m.bias.normal_(0.0, 0.2)
+    torch.save(head.state_dict(), wpath)
+    ctx = mp.get_context("spawn")
+    port = 39500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_head_worker, args=(r, 2, port, wpath, opath, dtype)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    parts = [torch.load(f"{opath}.{r}") for r in range(2)]
+    R.set_compute_dtype(dtype)
+    try:
+        ref = {k: v.cpu() for k, v in head.to("cuda:0").run(_pair().to("cuda:0")).items()}
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    from oracle import rf_oracle as O
+    st = {"m." + k: v.detach().float().cpu() for k, v in head.state_dict().items()}
+    ora = O.prediction_head(st, "m", _pair(), HNB)
+    for k in ("theta", "phi", "dist", "omega"):
+        got = torch.cat([p[k] for p in parts], 1)
+        err = ((got - ref[k]).abs().max() / ref[k].abs().max()).item()
+        err_o = ((got - ora[k]).abs().max() / ora[k].abs().max()).item()
+        print(f"\n[row shard head {dtype}] {k}: vs one process max-rel {err:.3e}, vs oracle {err_o:.3e}")
+        assert got.shape == ref[k].shape and err < tol and err_o < tol, (k, err, err_o)
