@@ -1046,11 +1046,11 @@ class PairUpdateWithAxialAttention(RFModule):
         self.layers = nn.ModuleList([PairUpdateWithAxialAttentionLayer(d_pair, d_ff, n_heads, p_dropout, performer_kws)
                                      for _ in range(n_encoder_layers)])
 
-    def run(self, x):
+    def run(self, x, row_group=None):
         xn = None
         for i, layer in enumerate(self.layers):
             nxt = self.layers[i + 1].layer[0].fn[0] if i + 1 < len(self.layers) else None
-            xn = layer.run(x, xn=xn, next_ln=nxt)
+            xn = layer.run(x, xn=xn, next_ln=nxt, row_group=row_group)
 
     def forward(self, x):
         x = fresh_f32(x)

@@ -126,7 +126,7 @@ def pair_axial_layer_row_sharded(layer, x_rows, group=None):
     from . import model as M
     g = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
     x = M.fresh_f32(x_rows)
-    layer.run(x, row_group=g)
+    layer.run(x, row_group=g)   # (a PairUpdateWithAxialAttention stack, rf.py:531-547, takes the same call)
     return x
 
 

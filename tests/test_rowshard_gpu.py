@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 if not torch.cuda.is_available():
     pytest.skip("needs a GPU", allow_module_level=True)
 
-D, H, L1, L2 = 96, 4, 48, 40
+D, H, L1, L2 = 96, 8, 48, 40
 CUT = 32  # rank 0: rows [0, 32), rank 1: rows [32, 48)
 
 
@@ -29,7 +29,7 @@ def _worker(rank, world, port, wpath, opath, dtype):
     import rosettafold_pytorch_amd as R
     from rosettafold_pytorch_amd import shard
     R.set_compute_dtype(dtype)
-    layer = R.PairUpdateWithAxialAttentionLayer(D, 2 * D, H, 0.0, {})
+    layer = R.PairUpdateWithAxialAttention(D, 2 * D, H, 0.0, 2)
     layer.load_state_dict(torch.load(wpath))
     layer = layer.to("cuda:0")
     lo, hi = (0, CUT) if rank == 0 else (CUT, L1)
@@ -46,7 +46,7 @@ def test_axial_layer_row_sharded_world2(tmp_path, dtype, tol):
     import rosettafold_pytorch_amd as R
     wpath, opath = str(tmp_path / "layer.pt"), str(tmp_path / "rows.pt")
     torch.manual_seed(77)
-    layer = R.PairUpdateWithAxialAttentionLayer(D, 2 * D, H, 0.0, {})
+    layer = R.PairUpdateWithAxialAttention(D, 2 * D, H, 0.0, 2)   # a stack of two axial layers (rf.py:531-547)
     torch.save(layer.state_dict(), wpath)
     ctx = mp.get_context("spawn")
     port = 35500 + os.getpid() % 2000
@@ -66,7 +66,7 @@ def test_axial_layer_row_sharded_world2(tmp_path, dtype, tol):
     # ... and against the CPU oracle's restatement of the reference layer on the whole tensor
     from oracle import rf_oracle as O
     st = {"m." + k: v.detach().float().cpu() for k, v in layer.state_dict().items()}
-    ora = O.pair_axial_layer(st, "m", _x(), H)
+    ora = O.pair_update_with_axial_attention(st, "m", _x(), 2)
     err_o = ((got - ora).abs().max() / ora.abs().max()).item()
     print(f"\n[row shard {dtype}] two row blocks (32 + 16 of 48): vs one process max-rel {err:.3e}, vs oracle {err_o:.3e}")
     assert got.shape == ref.shape and err < tol and err_o < tol, (err, err_o)
