@@ -1089,9 +1089,14 @@ class MsaUpdateWithPairLayer(RFModule):
         b = lin.weight.detach().float() @ lnm.bias.detach().float() + lin.bias.detach().float()
         return w, b
 
-    def run(self, msa, att, xn=None, next_ln=None):
+    def run(self, msa, att, xn=None, next_ln=None, row_group=None):
         """msa fp32 [B,N,L,D] in place; att: T [H,B,L,L] (softmax over the last dim); xn = msa2value pre-norm if the
-        previous GEMM produced it; returns next_ln(msa) or None."""
+        previous GEMM produced it; returns next_ln(msa) or None.
+        row_group: att holds this rank's rows [H,B,h,L] of the maps (pair-track row blocks, shard.shard_range); the values are
+        computed from the replicated msa, positions r0..r1 are updated here (attention + feed-forward) and the updated position
+        slices are all-gathered so that msa is whole again on every rank."""
+        if row_group is not None:
+            return self._run_rows(msa, att, xn, row_group)
         B, N, Lr, D = msa.shape
         H = self.n_heads
         dv = D // H
@@ -1109,13 +1114,47 @@ class MsaUpdateWithPairLayer(RFModule):
         return self.ff.fn[1].apply_residual(ln(self.ff.fn[0], msa), msa, next_ln)
 
 
-def pair_to_att(layers, pair):
+def _msa_update_rows(self, msa, att, xn, row_group):
+    """MsaUpdateWithPairLayer.run for a block of map rows (see there)."""
+    from . import shard
+    B, N, Lr, D = msa.shape
+    H = self.n_heads
+    dv = D // H
+    h = att.shape[2]
+    r0, r1 = shard.shard_range(Lr, shard.group_size(row_group), shard.group_rank(row_group))
+    if r1 - r0 != h:
+        raise ValueError(f"attention rows {h} do not match this rank's share {r1 - r0} of {Lr} positions")
+    v_t = torch.empty(B, N, D, Lr, device=msa.device, dtype=T())
+    lin = self.msa2value[1]
+    if xn is None:
+        xn = ln(self.msa2value[0], msa)
+    ops.gemm(self.wt("v", lin), xn, v_t, D, Lr, D, batch=(B * N, 1, 1), b_bs=(Lr * D, 0, 0),
+             c_bs=(D * Lr, 0, 0), c_row=(0, 0, Lr), bias=_f(lin.bias), bias_mode=L.BIAS_ROW)
+    rows = torch.empty(B, N, h, D, device=msa.device, dtype=F32)   # msa[:, :, r0:r1]
+    if h > 0:
+        ops.copy4d(msa, (N * Lr * D, Lr * D, D, 1), rows, (N * h * D, h * D, D, 1), (B, N, h, D), x_off=r0 * D)
+        ops.gemm(att, v_t, rows, h, N * dv, Lr, batch=(H, B, 1),
+                 a_bs=(B * h * Lr, h * Lr, 0), a_row=(0, 0, Lr),
+                 b_bs=(dv * Lr, N * D * Lr, 0), b_row=(dv, D * Lr, Lr),
+                 c_bs=(dv, N * h * D, 0), c_row=(0, 0, D), c_col=(dv, h * D), residual=rows)
+        self.ff.fn[1].apply_residual(ln(self.ff.fn[0], rows), rows, None)
+    shard.all_gather_positions(rows, msa, row_group)
+    return None
+
+
+MsaUpdateWithPairLayer._run_rows = _msa_update_rows
+
+
+def pair_to_att(layers, pair, row_group=None):
     """Shared front of the MsaUpdateWithPairLayer stack of one block (they all see the same pair):
     one symmetrise+normalise pass, one GEMM for every layer's head logits, per-(layer,head) softmax.
-    Returns a list of T [H,B,L,L]."""
+    Returns a list of T [H,B,L,L] ([H,B,h,L] for a block of h pair rows: row_group, the transposed sub-blocks of the
+    symmetrisation come from the other ranks)."""
     B, Lr, _, Dp = pair.shape
     H = layers[0].n_heads
     nl = len(layers)
+    if row_group is not None:
+        return _pair_rows_to_att(layers, pair, row_group)
     xs = ops.sym_layernorm(pair, T(), eps=layers[0].pair2att[1].eps)
     holder = layers[0]
 
@@ -1132,6 +1171,29 @@ def pair_to_att(layers, pair):
     return [att_all[li] for li in range(nl)]
 
 
+def _pair_rows_to_att(layers, pair, row_group):
+    from . import shard
+    B, h, Lr, Dp = pair.shape
+    H, nl = layers[0].n_heads, len(layers)
+    NH = nl * H
+    xt = shard.transpose_row_sharded(pair, row_group)
+    sym = ops.axpby(pair, 0.5, xt, 0.5, torch.empty_like(pair))
+    one, zero = ops.fill(torch.empty(Dp, device=pair.device, dtype=F32), 1.0), ops.zeros(Dp, device=pair.device, dtype=F32)
+    xs = ops.layernorm(sym, one, zero, eps=layers[0].pair2att[1].eps, out_dtype=T())   # no affine: folded into the projection
+    holder = layers[0]
+
+    def fold():
+        ws, bs = zip(*[l.folded_att_proj() for l in layers])
+        return torch.cat(ws, 0).to(T()).contiguous(), torch.cat(bs, 0).contiguous()
+
+    wc, bc = holder.cached(("att_fold", nl), fold)
+    logits = ops.linear(xs, wc, bc, out_dtype=F32)  # [B,h,L,nl*H]
+    att_all = torch.empty(nl, H, B, h, Lr, device=pair.device, dtype=T())
+    if h > 0:
+        ops.softmax_batched(logits, 1, Lr * NH, NH, att_all, B * h * Lr, Lr, B * h, Lr, NH)
+    return [att_all[li] for li in range(nl)]
+
+
 class MsaUpdateWithPair(RFModule):
     """rf.py:598-610 (the reference hides these layers in a plain list; here they are registered)."""
 
@@ -1140,13 +1202,14 @@ class MsaUpdateWithPair(RFModule):
         self.encoder_layers = nn.ModuleList([MsaUpdateWithPairLayer(d_msa, d_pair, n_heads, p_dropout)
                                              for _ in range(n_encoder_layers)])
 
-    def run(self, msa, pair):
+    def run(self, msa, pair, row_group=None):
+        """msa fp32 [B,N,L,D] in place (replicated on every rank of row_group); pair: the whole tensor, or this rank's rows."""
         layers = list(self.encoder_layers)
-        atts = pair_to_att(layers, pair)
+        atts = pair_to_att(layers, pair, row_group)
         xn = None
         for i, (layer, att) in enumerate(zip(layers, atts)):
             nxt = layers[i + 1].msa2value[0] if i + 1 < len(layers) else None
-            xn = layer.run(msa, att, xn=xn, next_ln=nxt)
+            xn = layer.run(msa, att, xn=xn, next_ln=nxt, row_group=row_group)
 
     def forward(self, msa, pair):
         msa = fresh_f32(msa)

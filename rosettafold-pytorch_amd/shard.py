@@ -238,3 +238,51 @@ def prediction_head_row_sharded(head, pair_rows, group=None):
     g = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
     return head.run(pair_rows.float().contiguous(), row_group=g)
 
+
+def group_size(group=None):
+    return dist.get_world_size(group) if dist.is_initialized() else 1
+
+
+def group_rank(group=None):
+    return dist.get_rank(group) if dist.is_initialized() else 0
+
+
+def all_gather_positions(rows, full, group=None):
+    """rows: fp32 [B, N, h, D] = positions shard_range(L, world, rank) of full [B, N, L, D]; writes every rank's slice into
+    `full` on every rank (one all_gather of slices padded to the largest share; placement by rf_copy4d)."""
+    from . import ops
+    B, N, h, D = rows.shape
+    Lr = full.shape[2]
+    n, r = group_size(group), group_rank(group)
+    if n == 1:
+        ops.copy4d(rows, (N * h * D, h * D, D, 1), full, (N * Lr * D, Lr * D, D, 1), (B, N, h, D))
+        return full
+    hmax = max(shard_range(Lr, n, k)[1] - shard_range(Lr, n, k)[0] for k in range(n))
+    host = dist.get_backend(group) == "gloo"
+    send = ops.zeros(B, N, hmax, D, device=rows.device, dtype=rows.dtype)
+    if h > 0:
+        ops.copy4d(rows, (N * h * D, h * D, D, 1), send, (N * hmax * D, hmax * D, D, 1), (B, N, h, D))
+    if host:
+        send = send.cpu()
+    else:
+        torch.cuda.current_stream().synchronize()
+    bufs = [torch.empty_like(send) for _ in range(n)]
+    dist.all_gather(bufs, send, group=group)
+    for k, buf in enumerate(bufs):
+        k0, k1 = shard_range(Lr, n, k)
+        if k1 > k0:
+            ops.copy4d(buf.to(full.device), (N * hmax * D, hmax * D, D, 1), full, (N * Lr * D, Lr * D, D, 1),
+                       (B, N, k1 - k0, D), y_off=k0 * D)
+    return full
+
+
+def msa_update_with_pair_row_sharded(module, msa, pair_rows, group=None):
+    """MsaUpdateWithPair (rf.py:550-610) with the pair tensor held as row blocks: msa [B,N,L,D] is replicated, pair_rows are this
+    rank's rows shard_range(L, world, rank).  Exchanges: the transposed sub-blocks of the symmetrisation (once per block of
+    layers) and one all-gather of the updated msa positions per layer.  Returns the updated msa (whole, fp32) on every rank."""
+    from . import model as M
+    g = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
+    out = M.fresh_f32(msa)
+    module.run(out, pair_rows.float().contiguous(), row_group=g)
+    return out
+

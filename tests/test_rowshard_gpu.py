@@ -198,3 +198,64 @@ def test_prediction_head_row_sharded_world2(tmp_path, dtype, tol):
         err_o = ((got - ora[k]).abs().max() / ora[k].abs().max()).item()
         print(f"\n[row shard head {dtype}] {k}: vs one process max-rel {err:.3e}, vs oracle {err_o:.3e}")
         assert got.shape == ref[k].shape and err < tol and err_o < tol, (k, err, err_o)
+
+
+# ---- MsaUpdateWithPair with the pair tensor on row blocks: transposed exchange + per-layer all-gather of msa positions -----
+MD, MP, MH, MN, ML = 96, 64, 4, 6, 48   # (16-bit attention maps want L % 8 == 0, like the unsharded path)
+
+
+def _msa_pair():
+    g = torch.Generator().manual_seed(17)
+    return torch.randn(1, MN, ML, MD, generator=g), torch.randn(1, ML, ML, MP, generator=g)
+
+
+def _mup_worker(rank, world, port, wpath, opath, dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rosettafold_pytorch_amd as R
+    from rosettafold_pytorch_amd import shard
+    R.set_compute_dtype(dtype)
+    mod = R.MsaUpdateWithPair(MD, MP, MH, n_encoder_layers=2, p_dropout=0.0)
+    mod.load_state_dict(torch.load(wpath))
+    mod = mod.to("cuda:0")
+    msa, pair = _msa_pair()
+    lo, hi = shard.shard_range(ML, world, rank)
+    out = shard.msa_update_with_pair_row_sharded(mod, msa.to("cuda:0"), pair[:, lo:hi].to("cuda:0"))
+    torch.cuda.synchronize()
+    torch.save(out.cpu(), f"{opath}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)],
+                         ids=["fp32", "bf16", "fp16"])
+def test_msa_update_with_pair_row_sharded_world2(tmp_path, dtype, tol):
+    import rosettafold_pytorch_amd as R
+    wpath, opath = str(tmp_path / "mup.pt"), str(tmp_path / "msa.pt")
+    torch.manual_seed(80)
+    mod = R.MsaUpdateWithPair(MD, MP, MH, n_encoder_layers=2, p_dropout=0.0)
+    torch.save(mod.state_dict(), wpath)
+    ctx = mp.get_context("spawn")
+    port = 41500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_mup_worker, args=(r, 2, port, wpath, opath, dtype)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    outs = [torch.load(f"{opath}.{r}") for r in range(2)]
+    assert torch.equal(outs[0], outs[1]), "the all-gather leaves the same msa on every rank"
+    msa, pair = _msa_pair()
+    R.set_compute_dtype(dtype)
+    try:
+        ref = mod.to("cuda:0")(msa.to("cuda:0"), pair.to("cuda:0")).cpu()
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    from oracle import rf_oracle as O
+    st = {"m." + k: v.detach().float().cpu() for k, v in mod.state_dict().items()}
+    ora = O.msa_update_with_pair(st, "m", msa, pair, 2, MH)
+    err = ((outs[0] - ref).abs().max() / ref.abs().max()).item()
+    err_o = ((outs[0] - ora).abs().max() / ora.abs().max()).item()
+    print(f"\n[row shard msa-update-with-pair {dtype}] pair rows 24 + 24 of 48: vs one process max-rel {err:.3e}, vs oracle {err_o:.3e}")
+    assert err < tol and err_o < tol, (err, err_o)
