@@ -894,6 +894,18 @@ class OuterProductMean(RFModule):
             cn = ln(lnm, co)
         return ops.linear(cn, self.wt("w", self.to_out[1]), _f(self.to_out[1].bias), out_dtype=F32)
 
+    def run_rows(self, x_rows_t, y_t, N):
+        """x_rows_t: T [B, h, P, N] (a block of rows), y_t: T [B, L, P, N] -> fp32 [B, h, L, out]: the general path of run()
+        on a rectangular block (pair-track row-block sharding)."""
+        B, h, P, _ = x_rows_t.shape
+        Lr = y_t.shape[1]
+        PP = P * P
+        lnm = self.to_out[0]
+        co = torch.empty(B, h, Lr, PP, device=x_rows_t.device, dtype=T())
+        ops.gemm(x_rows_t, y_t, co, h * P, Lr * P, N, batch=(B, 1, 1), a_bs=(h * P * N, 0, 0), b_bs=(Lr * P * N, 0, 0),
+                 c_bs=(h * Lr * PP, 0, 0), c_row=(P, Lr * PP, P), c_col=(P, PP))
+        return ops.linear(ln(lnm, co), self.wt("w", self.to_out[1]), _f(self.to_out[1].bias), out_dtype=F32)
+
     def forward(self, x, y=None):
         y = x if y is None else y
         B, N, Lr, P = x.shape
@@ -934,10 +946,11 @@ class PairUpdateWithMsa(RFModule):
             nn.ELU(),
         )
 
-    def run(self, msa, pair, att):
-        """msa fp32 [B,N,L,D], pair fp32 [B,L,L,Dp], att fp32 [B,L,L,H] -> new pair fp32."""
+    def _msa_operands(self, msa):
+        """Per-position features of the MSA: (msa1d fp32 [B,L,2P], x_t, y_t T [B,L,P,Np] = the transposed operands of the outer
+        product, Np)."""
         B, N, Lr, D = msa.shape
-        P, Dp = self.d_proj, self.d_pair
+        P = self.d_proj
         dev = msa.device
         Np = pad8(N)
         mp_pre = ops.linear(ln(self.proj_msa[0], msa), self.wt("p", self.proj_msa[1]), _f(self.proj_msa[1].bias),
@@ -956,6 +969,53 @@ class PairUpdateWithMsa(RFModule):
         yt = mk(B, Lr, P, Np, device=dev, dtype=T())
         for src, dst in ((mp, xt), (mpw, yt)):
             ops.copy4d(src, (N * Lr * P, P, 1, Lr * P), dst, (Lr * P * Np, P * Np, Np, 1), (B, Lr, P, N))
+        return msa1d, xt, yt, Np
+
+    def run_rows(self, msa, pair_rows, att, row_group):
+        """run() for a block of pair rows (pair-track row-block sharding, shard.pair_update_with_msa_row_sharded): msa
+        [B,N,L,D] and att [B,L,L,H] are replicated, pair_rows fp32 [B,h,L,Dp] are this rank's rows shard_range(L, world, rank).
+        The outer product, the feature assembly and the projection are local to the rows; the two 3x3 convolutions fetch one
+        halo row from each neighbour and the two InstanceNorms all-reduce their sums.  Returns the new rows (fp32)."""
+        from . import shard
+        B, N, Lr, D = msa.shape
+        P, Dp = self.d_proj, self.d_pair
+        dev = msa.device
+        h = pair_rows.shape[1]
+        r0, r1 = shard.shard_range(Lr, shard.group_size(row_group), shard.group_rank(row_group))
+        if r1 - r0 != h or h == 0:
+            raise ValueError(f"pair rows {h} do not match this rank's (non-empty) share {r1 - r0} of {Lr}")
+        msa1d, xt, yt, Np = self._msa_operands(msa)
+        Kf = pad8(self.d_feat)
+        feat = ops.zeros(B, h, Lr, Kf, device=dev, dtype=T())
+        # outer product of this block's rows with every column: the general GEMM form (the fused kernel walks square pictures)
+        xr = ops.copy4d(xt, (Lr * P * Np, P * Np, Np, 1), torch.empty(B, h, P, Np, device=dev, dtype=T()),
+                        (h * P * Np, P * Np, Np, 1), (B, h, P, Np), x_off=r0 * P * Np)
+        coevol = self.outer_product_mean.run_rows(xr, yt, Np)  # fp32 [B,h,L,Dp]
+        ln(self.ln_coevol_feat, coevol, out=feat, out_ld=Kf, out_off=0)
+        # feat[b,i,j, Dp + c] = msa1d[b, r0 + i, c] ; feat[b,i,j, Dp + 2P + c] = msa1d[b, j, c]   (rf_tile_1d_feats on a block)
+        fs = (h * Lr * Kf, Lr * Kf, Kf, 1)
+        ops.copy4d(msa1d, (Lr * 2 * P, 2 * P, 0, 1), feat, fs, (B, h, Lr, 2 * P), x_off=r0 * 2 * P, y_off=Dp)
+        ops.copy4d(msa1d, (Lr * 2 * P, 0, 2 * P, 1), feat, fs, (B, h, Lr, 2 * P), y_off=Dp + 2 * P)
+        ln(self.ln_pair, pair_rows, out=feat, out_ld=Kf, out_off=Dp + 4 * P)
+        H = att.shape[-1]
+        ops.copy4d(att.contiguous(), (Lr * Lr * H, Lr * H, H, 1), feat, fs, (B, h, Lr, H), x_off=r0 * Lr * H, y_off=2 * Dp + 4 * P)
+        x = ops.linear(feat, self.wt("f", self.resnet[0], kpad=Kf), _f(self.resnet[0].bias), out_dtype=F32)
+        blk = self.resnet[1].fn
+        kw = {"row_group": row_group, "rows_global": Lr}
+        conv = lambda key, c, t: shard.drop_row_halos(conv3x3(self, key, c, shard.exchange_row_halos(t, 1, row_group), 1), 1)  # noqa: E731
+        y = conv("c1", blk[1], ops.cast(x, T()))
+        y, _ = ops.instnorm(y, _f(blk[2].weight), _f(blk[2].bias), eps=blk[2].eps, act=L.ACT_ELU, out_dtype=T(), **kw)
+        y = conv("c2", blk[5], y)
+        out, _ = ops.instnorm(y, _f(blk[6].weight), _f(blk[6].bias), eps=blk[6].eps, residual=x, act=L.ACT_ELU,
+                              out_dtype=F32, **kw)
+        return out
+
+    def run(self, msa, pair, att):
+        """msa fp32 [B,N,L,D], pair fp32 [B,L,L,Dp], att fp32 [B,L,L,H] -> new pair fp32."""
+        B, N, Lr, D = msa.shape
+        P, Dp = self.d_proj, self.d_pair
+        dev = msa.device
+        msa1d, xt, yt, Np = self._msa_operands(msa)
         # feature tensor (K padded to a multiple of 8)
         Kf = pad8(self.d_feat)
         feat = torch.empty(B, Lr, Lr, Kf, device=dev, dtype=T())  # every feature column is written below; only the K padding

@@ -286,3 +286,11 @@ def msa_update_with_pair_row_sharded(module, msa, pair_rows, group=None):
     module.run(out, pair_rows.float().contiguous(), row_group=g)
     return out
 
+
+def pair_update_with_msa_row_sharded(module, msa, pair_rows, att, group=None):
+    """PairUpdateWithMsa (rf.py:430-498) with the pair tensor held as row blocks: msa [B,N,L,D] and the tied-attention map att
+    [B,L,L,H] are replicated, pair_rows are this rank's rows shard_range(L, world, rank).  Exchanges: one halo row per
+    neighbour and convolution, 2*B*C doubles per InstanceNorm.  Returns the new rows (fp32)."""
+    g = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
+    return module.run_rows(msa.float().contiguous(), pair_rows.float().contiguous(), att.float().contiguous(), g)
+

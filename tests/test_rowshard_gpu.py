@@ -259,3 +259,69 @@ def test_msa_update_with_pair_row_sharded_world2(tmp_path, dtype, tol):
     err_o = ((outs[0] - ora).abs().max() / ora.abs().max()).item()
     print(f"\n[row shard msa-update-with-pair {dtype}] pair rows 24 + 24 of 48: vs one process max-rel {err:.3e}, vs oracle {err_o:.3e}")
     assert err < tol and err_o < tol, (err, err_o)
+
+
+# ---- PairUpdateWithMsa on row blocks: rectangular outer product + feature assembly, halo rows, InstanceNorm sums ------------
+UD, UPJ, UP, UH, UN, UL = 96, 32, 64, 4, 8, 48
+
+
+def _pum_inputs():
+    g = torch.Generator().manual_seed(19)
+    msa, pair = torch.randn(1, UN, UL, UD, generator=g), torch.randn(1, UL, UL, UP, generator=g)
+    return msa, pair, torch.rand(1, UL, UL, UH, generator=g).softmax(2)
+
+
+def _pum_worker(rank, world, port, wpath, opath, dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rosettafold_pytorch_amd as R
+    from rosettafold_pytorch_amd import shard
+    R.set_compute_dtype(dtype)
+    mod = R.PairUpdateWithMsa(d_msa=UD, d_proj=UPJ, d_pair=UP, n_heads=UH, p_dropout=0.0)
+    mod.load_state_dict(torch.load(wpath))
+    mod = mod.to("cuda:0")
+    msa, pair, att = _pum_inputs()
+    lo, hi = shard.shard_range(UL, world, rank)
+    out = shard.pair_update_with_msa_row_sharded(mod, msa.to("cuda:0"), pair[:, lo:hi].to("cuda:0"), att.to("cuda:0"))
+    torch.cuda.synchronize()
+    torch.save(out.cpu(), f"{opath}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)],
+                         ids=["fp32", "bf16", "fp16"])
+def test_pair_update_with_msa_row_sharded_world2(tmp_path, dtype, tol):
+    import rosettafold_pytorch_amd as R
+    wpath, opath = str(tmp_path / "pum.pt"), str(tmp_path / "rows.pt")
+    torch.manual_seed(81)
+    mod = R.PairUpdateWithMsa(d_msa=UD, d_proj=UPJ, d_pair=UP, n_heads=UH, p_dropout=0.0)
+    with torch.no_grad():
+        for m in mod.modules():
+            if isinstance(m, torch.nn.InstanceNorm2d):
+                m.weight.normal_(1.0, 0.2)
+                m.bias.normal_(0.0, 0.2)
+    torch.save(mod.state_dict(), wpath)
+    ctx = mp.get_context("spawn")
+    port = 43500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_pum_worker, args=(r, 2, port, wpath, opath, dtype)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    got = torch.cat([torch.load(f"{opath}.{r}") for r in range(2)], 1)
+    msa, pair, att = _pum_inputs()
+    R.set_compute_dtype(dtype)
+    try:
+        ref = mod.to("cuda:0")(msa.to("cuda:0"), pair.to("cuda:0"), att.to("cuda:0")).cpu()
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    from oracle import rf_oracle as O
+    st = {"m." + k: v.detach().float().cpu() for k, v in mod.state_dict().items()}
+    ora = O.pair_update_with_msa(st, "m", msa, pair, att)
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    err_o = ((got - ora).abs().max() / ora.abs().max()).item()
+    print(f"\n[row shard pair-update-with-msa {dtype}] rows 24 + 24 of 48: vs one process max-rel {err:.3e}, vs oracle {err_o:.3e}")
+    assert got.shape == ref.shape and err < tol and err_o < tol, (err, err_o)
