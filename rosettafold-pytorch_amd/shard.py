@@ -294,3 +294,12 @@ def pair_update_with_msa_row_sharded(module, msa, pair_rows, att, group=None):
     g = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
     return module.run_rows(msa.float().contiguous(), pair_rows.float().contiguous(), att.float().contiguous(), g)
 
+
+def two_track_block_row_sharded(block, msa, pair_rows, group=None):
+    """TwoTrackBlock (rf.py:923-968) with the pair tensor held as row blocks: msa [B,N,L,D] replicated in, replicated out;
+    pair_rows = rows shard_range(L, world, rank) in, the same rows out.  Returns (msa, pair_rows), both fp32."""
+    from . import model as M
+    g = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
+    m = M.fresh_f32(msa)
+    return m, block.run(m, pair_rows.float().contiguous(), row_group=g)
+

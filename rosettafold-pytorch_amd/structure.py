@@ -404,12 +404,20 @@ class TwoTrackBlock(RFModule):
         self.msa_update_with_pair = MsaUpdateWithPair(d_msa=d_msa, d_pair=d_pair, n_heads=4,
                                                       n_encoder_layers=n_encoder_layers, p_dropout=p_dropout)
 
-    def run(self, msa, pair):
-        """msa updated in place; returns the new pair tensor."""
+    def run(self, msa, pair, row_group=None):
+        """msa updated in place; returns the new pair tensor.
+        row_group: `pair` is this rank's block of rows shard_range(L, world, rank) of the pair tensor, msa is replicated
+        (pair-track row-block sharding, shard.two_track_block_row_sharded): the MSA self-attention runs on every rank, the three
+        pair-track modules run on the row block with their exchanges."""
         att = self.msa_update_using_self_att.run(msa)
-        pair = self.pair_update_with_msa.run(msa, pair, att)
-        self.pair_update_with_axial_attention.run(pair)
-        self.msa_update_with_pair.run(msa, pair)
+        if row_group is None:
+            pair = self.pair_update_with_msa.run(msa, pair, att)
+            self.pair_update_with_axial_attention.run(pair)
+            self.msa_update_with_pair.run(msa, pair)
+            return pair
+        pair = self.pair_update_with_msa.run_rows(msa, pair, att, row_group)
+        self.pair_update_with_axial_attention.run(pair, row_group=row_group)
+        self.msa_update_with_pair.run(msa, pair, row_group=row_group)
         return pair
 
     def forward(self, msa, pair):

@@ -325,3 +325,65 @@ def test_pair_update_with_msa_row_sharded_world2(tmp_path, dtype, tol):
     err_o = ((got - ora).abs().max() / ora.abs().max()).item()
     print(f"\n[row shard pair-update-with-msa {dtype}] rows 24 + 24 of 48: vs one process max-rel {err:.3e}, vs oracle {err_o:.3e}")
     assert got.shape == ref.shape and err < tol and err_o < tol, (err, err_o)
+
+
+# ---- a whole TwoTrackBlock with the pair tensor on row blocks (rf.py:923-968) -------------------------------------------------
+TM, TP, TN, TL = 96, 72, 8, 48
+
+
+def _ttb_inputs():
+    g = torch.Generator().manual_seed(23)
+    return torch.randn(1, TN, TL, TM, generator=g), torch.randn(1, TL, TL, TP, generator=g)
+
+
+def _ttb_worker(rank, world, port, wpath, opath, dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rosettafold_pytorch_amd as R
+    from rosettafold_pytorch_amd import shard
+    R.set_compute_dtype(dtype)
+    blk = R.TwoTrackBlock(TM, TP, 1, 0.0)
+    blk.load_state_dict(torch.load(wpath))
+    blk = blk.to("cuda:0")
+    msa, pair = _ttb_inputs()
+    lo, hi = shard.shard_range(TL, world, rank)
+    m, p = shard.two_track_block_row_sharded(blk, msa.to("cuda:0"), pair[:, lo:hi].to("cuda:0"))
+    torch.cuda.synchronize()
+    torch.save({"msa": m.cpu(), "pair": p.cpu()}, f"{opath}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.float16, 1e-2)], ids=["fp32", "fp16"])
+def test_two_track_block_row_sharded_world2(tmp_path, dtype, tol):
+    import rosettafold_pytorch_amd as R
+    wpath, opath = str(tmp_path / "ttb.pt"), str(tmp_path / "out.pt")
+    torch.manual_seed(82)
+    blk = R.TwoTrackBlock(TM, TP, 1, 0.0)
+    torch.save(blk.state_dict(), wpath)
+    ctx = mp.get_context("spawn")
+    port = 45500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ttb_worker, args=(r, 2, port, wpath, opath, dtype)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    outs = [torch.load(f"{opath}.{r}") for r in range(2)]
+    assert torch.equal(outs[0]["msa"], outs[1]["msa"]), "msa is replicated again after the block"
+    pair_got = torch.cat([o["pair"] for o in outs], 1)
+    msa, pair = _ttb_inputs()
+    R.set_compute_dtype(dtype)
+    try:
+        rm, rp = blk.to("cuda:0")(msa.to("cuda:0"), pair.to("cuda:0"))
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    from oracle import rf_oracle as O
+    st = {"m." + k: v.detach().float().cpu() for k, v in blk.state_dict().items()}
+    om, op = O.two_track_block(st, "m", msa, pair, 1)
+    e = lambda a, b: ((a.cpu() - b.cpu()).abs().max() / b.abs().max()).item()  # noqa: E731
+    errs = {"msa vs one process": e(outs[0]["msa"], rm), "pair vs one process": e(pair_got, rp),
+            "msa vs oracle": e(outs[0]["msa"], om), "pair vs oracle": e(pair_got, op)}
+    print(f"\n[row shard two-track block {dtype}] " + ", ".join(f"{k} {v:.3e}" for k, v in errs.items()))
+    assert all(v < tol for v in errs.values()), errs
