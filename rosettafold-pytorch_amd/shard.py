@@ -303,3 +303,40 @@ def two_track_block_row_sharded(block, msa, pair_rows, group=None):
     m = M.fresh_f32(msa)
     return m, block.run(m, pair_rows.float().contiguous(), row_group=g)
 
+
+def take_rows(full, group=None):
+    """This rank's rows shard_range(L, world, rank) of a replicated [B, L, ...] tensor, as a contiguous copy."""
+    from . import ops
+    B, Lr = full.shape[:2]
+    inner = full.numel() // max(B * Lr, 1)
+    r0, r1 = shard_range(Lr, group_size(group), group_rank(group))
+    h = r1 - r0
+    out = torch.empty((B, h) + tuple(full.shape[2:]), device=full.device, dtype=full.dtype)
+    if h > 0:
+        ops.copy4d(full.contiguous(), (Lr * inner, inner, 0, 1), out, (h * inner, inner, 0, 1), (B, h, 1, inner), x_off=r0 * inner)
+    return out
+
+
+def all_gather_rows(rows, group=None):
+    """rows [B, h, L, C] (shard_range(L, world, rank) of a square picture) -> the whole [B, L, L, C] on every rank."""
+    B, h, Lr, Cc = rows.shape
+    full = torch.empty(B, Lr, Lr, Cc, device=rows.device, dtype=rows.dtype)
+    all_gather_positions(rows.view(B, 1, h, Lr * Cc), full.view(B, 1, Lr, Lr * Cc), group)
+    return full
+
+
+def forward_row_sharded(model, msa, seq, aa_idx, group=None):
+    """RoseTTAFold.forward (rf.py:1273-1289) of ONE batch spread over the ranks of `group` by pair-track row blocks -- the
+    configuration the reference cannot shard at all (BASELINE configs[3]: B = 1, L = 1024).  Every rank passes the same
+    inputs.  Returns (logits, xyz, plddt) like forward(), the logit maps holding this rank's rows shard_range(L, world, rank)."""
+    from . import model as M, structure as S
+    g = group if group is not None else (dist.group.WORLD if dist.is_initialized() else None)
+    dev = next(model.parameters()).device
+    msa, seq, aa_idx = msa.to(dev).contiguous(), seq.to(dev).contiguous(), aa_idx.to(dev).contiguous()
+    mono = M.check_index_range(msa, seq, aa_idx, model.msa_emb.to_embedding.num_embeddings,
+                               min(model.msa_emb.pos_enc.max_len, model.pair_emb.pos_enc.max_len))
+    with torch.no_grad():
+        out = model.forward_validated(msa, seq, aa_idx, mono, row_group=g)
+    S.check_edge_capacity()
+    return out
+

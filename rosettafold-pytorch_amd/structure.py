@@ -388,6 +388,14 @@ class MsaUpdateWithPairAndCoord(RFModule):
 # ================================================================================================
 # blocks and model
 # ================================================================================================
+def _whole_pair(pair, row_group):
+    """The whole pair tensor on every rank from the row blocks (identity without a row group)."""
+    if row_group is None:
+        return pair
+    from . import shard
+    return shard.all_gather_rows(pair, row_group)
+
+
 class TwoTrackBlock(RFModule):
     """rf.py:923-968."""
 
@@ -438,9 +446,11 @@ class ThreeTrackBlock(TwoTrackBlock):
                                                                         d_ff=d_msa * 4, distance_bins=[8, 12, 16, 20],
                                                                         p_dropout=p_dropout)
 
-    def run3(self, msa, pair, xyz, seq_onehot, aa_idx, monotonic=True):
-        pair = self.run(msa, pair)
-        state, xyz = self.coord_update_with_msa_and_pair.run(xyz, msa, pair, aa_idx, seq_onehot, monotonic)
+    def run3(self, msa, pair, xyz, seq_onehot, aa_idx, monotonic=True, row_group=None):
+        """row_group: `pair` is this rank's block of rows (TwoTrackBlock.run); the structure track runs replicated on the
+        all-gathered pair tensor (it reads the pair rows of the kNN edges of every residue)."""
+        pair = self.run(msa, pair, row_group)
+        state, xyz = self.coord_update_with_msa_and_pair.run(xyz, msa, _whole_pair(pair, row_group), aa_idx, seq_onehot, monotonic)
         msa = self.msa_update_with_pair_and_coord.run(xyz, state, msa)
         return msa, pair, xyz
 
@@ -462,9 +472,9 @@ class FinalBlock(TwoTrackBlock):
                                                                         n_neighbors=n_neighbors, p_dropout=p_dropout)
         self.plddt_head = Linear(d_state, 1)
 
-    def run3(self, msa, pair, xyz, seq_onehot, aa_idx, monotonic=True):
-        pair = self.run(msa, pair)
-        state, xyz = self.coord_update_with_msa_and_pair.run(xyz, msa, pair, aa_idx, seq_onehot, monotonic)
+    def run3(self, msa, pair, xyz, seq_onehot, aa_idx, monotonic=True, row_group=None):
+        pair = self.run(msa, pair, row_group)
+        state, xyz = self.coord_update_with_msa_and_pair.run(xyz, msa, _whole_pair(pair, row_group), aa_idx, seq_onehot, monotonic)
         plddt = ops.linear(state.contiguous(), self.plddt_head.weight.detach(), _f(self.plddt_head.bias), out_dtype=F32)
         return msa, pair, xyz, plddt[..., 0]
 
@@ -515,20 +525,26 @@ class RoseTTAFold(RFModule):
             return out
 
     @torch.no_grad()
-    def forward_validated(self, msa, seq, aa_idx, mono=True):
+    def forward_validated(self, msa, seq, aa_idx, mono=True, row_group=None):
         """forward() behind the input validation: launches only, no host read of device data, so it can be recorded into
-        a hipGraph (graph.GraphedForward).  `mono` = aa_idx strictly increasing in every sample (what forward() checks)."""
+        a hipGraph (graph.GraphedForward).  `mono` = aa_idx strictly increasing in every sample (what forward() checks).
+        row_group: ONE sample spread over the ranks of a torch.distributed group (shard.forward_row_sharded): every rank gets the
+        same inputs, the pair track runs on row blocks shard_range(L, world, rank), the MSA and structure tracks are replicated;
+        returns this rank's rows of the logit maps and the whole xyz / plddt."""
         with torch.cuda.device(msa.device):
             m = self.msa_emb.run(msa, aa_idx)
             p = self.pair_emb.run(seq, aa_idx)
+            if row_group is not None:
+                from . import shard
+                p = shard.take_rows(p, row_group)
             onehot = ops.onehot(seq, 21)  # rf.py:1276
             for blk in self.two_track_blocks:
-                p = blk.run(m, p)
-            xyz = self.initial_coord_generation_with_msa_and_pair.run(m, p, onehot, aa_idx)
+                p = blk.run(m, p, row_group)
+            xyz = self.initial_coord_generation_with_msa_and_pair.run(m, _whole_pair(p, row_group), onehot, aa_idx)
             for blk in self.three_track_blocks:
-                m, p, xyz = blk.run3(m, p, xyz, onehot, aa_idx, mono)
-            m, p, xyz, plddt = self.final_block.run3(m, p, xyz, onehot, aa_idx, mono)
-            logits = self.prediction_head.run(p)
+                m, p, xyz = blk.run3(m, p, xyz, onehot, aa_idx, mono, row_group)
+            m, p, xyz, plddt = self.final_block.run3(m, p, xyz, onehot, aa_idx, mono, row_group)
+            logits = self.prediction_head.run(p, row_group)
         return logits, xyz, plddt
 
 

@@ -387,3 +387,63 @@ def test_two_track_block_row_sharded_world2(tmp_path, dtype, tol):
             "msa vs oracle": e(outs[0]["msa"], om), "pair vs oracle": e(pair_got, op)}
     print(f"\n[row shard two-track block {dtype}] " + ", ".join(f"{k} {v:.3e}" for k, v in errs.items()))
     assert all(v < tol for v in errs.values()), errs
+
+
+# ---- the whole forward, ONE sample over two ranks (the case the reference cannot shard: configs[3] is B = 1) ---------------------
+FCFG = dict(d_input=21, d_msa=96, d_pair=72, d_node=8, d_edge=8, d_state=8, n_two_track_blocks=1, n_three_track_blocks=2,
+            n_encoder_layers=1, max_len=64, n_neighbors=[16, 16], p_dropout=0.0)
+FN, FL = 8, 32
+
+
+def _f_inputs():
+    g = torch.Generator().manual_seed(29)
+    msa = torch.randint(0, 21, (1, FN, FL), generator=g)
+    return msa, msa[:, 0].clone(), torch.arange(FL).unsqueeze(0)
+
+
+def _f_worker(rank, world, port, ckpt, opath, dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import rosettafold_pytorch_amd as R
+    from rosettafold_pytorch_amd import shard
+    R.set_compute_dtype(dtype)
+    model = R.RoseTTAFold(**FCFG)
+    R.load_checkpoint(model, ckpt)
+    model = model.to("cuda:0")
+    logits, xyz, plddt = shard.forward_row_sharded(model, *_f_inputs())
+    torch.cuda.synchronize()
+    torch.save({"logits": {k: v.cpu() for k, v in logits.items()}, "xyz": xyz.cpu(), "plddt": plddt.cpu()}, f"{opath}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_forward_row_sharded_world2(tmp_path):
+    import rosettafold_pytorch_amd as R
+    ckpt, opath = str(tmp_path / "model.pt"), str(tmp_path / "out.pt")
+    torch.manual_seed(83)
+    model = R.RoseTTAFold(**FCFG)
+    R.save_checkpoint(model, ckpt)
+    ctx = mp.get_context("spawn")
+    port = 47500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_f_worker, args=(r, 2, port, ckpt, opath, torch.float32)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    outs = [torch.load(f"{opath}.{r}") for r in range(2)]
+    assert torch.equal(outs[0]["xyz"], outs[1]["xyz"]) and torch.equal(outs[0]["plddt"], outs[1]["plddt"]), \
+        "the replicated structure track sees the same gathered pair tensor on every rank"
+    R.set_compute_dtype(torch.float32)
+    try:
+        rl, rx, rp = model.to("cuda:0")(*[t.cuda() for t in _f_inputs()])
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    e = lambda a, b: ((a.cpu() - b.cpu()).abs().max() / b.abs().max().clamp_min(1e-20)).item()  # noqa: E731
+    errs = {k: e(torch.cat([o["logits"][k] for o in outs], 1), rl[k]) for k in rl}
+    errs["xyz"], errs["plddt"] = e(outs[0]["xyz"], rx), e(outs[0]["plddt"], rp)
+    print("\n[row shard forward fp32] one sample over two ranks vs one process: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert all(v < 1e-3 for v in errs.values()), errs
+    for k in rl:   # ... and the distogram argmax bins are the single-process ones
+        assert torch.equal(torch.cat([o["logits"][k] for o in outs], 1).argmax(-1), rl[k].cpu().argmax(-1)), k
