@@ -901,10 +901,19 @@ class OuterProductMean(RFModule):
         Lr = y_t.shape[1]
         PP = P * P
         lnm = self.to_out[0]
-        co = torch.empty(B, h, Lr, PP, device=x_rows_t.device, dtype=T())
-        ops.gemm(x_rows_t, y_t, co, h * P, Lr * P, N, batch=(B, 1, 1), a_bs=(h * P * N, 0, 0), b_bs=(Lr * P * N, 0, 0),
-                 c_bs=(h * Lr * PP, 0, 0), c_row=(P, Lr * PP, P), c_col=(P, PP))
-        return ops.linear(ln(lnm, co), self.wt("w", self.to_out[1]), _f(self.to_out[1].bias), out_dtype=F32)
+        out = torch.empty(B, h, Lr, self.to_out[1].weight.shape[0], device=x_rows_t.device, dtype=F32)
+        # in slabs of rows: the P*P-wide intermediate of a slab stays under 2^28 elements (rf_gemm rejects the 512 x 1024 block of a
+        # two-rank split at L = 1024 in one piece; the slab also bounds the 0.5 GB-per-256-rows intermediate)
+        step = max(1, (1 << 28) // (Lr * PP * B))
+        for i0 in range(0, h, step):
+            hs = min(step, h - i0)
+            co = torch.empty(B, hs, Lr, PP, device=x_rows_t.device, dtype=T())
+            for b in range(B):
+                ops.gemm(x_rows_t[b, i0:i0 + hs], y_t[b], co[b], hs * P, Lr * P, N, c_row=(P, Lr * PP, P), c_col=(P, PP))
+            y = ops.linear(ln(lnm, co), self.wt("w", self.to_out[1]), _f(self.to_out[1].bias), out_dtype=F32)
+            ops.copy4d(y, (hs * Lr * y.shape[-1], Lr * y.shape[-1], y.shape[-1], 1), out,
+                       (h * Lr * y.shape[-1], Lr * y.shape[-1], y.shape[-1], 1), (B, hs, Lr, y.shape[-1]), y_off=i0 * Lr * y.shape[-1])
+        return out
 
     def forward(self, x, y=None):
         y = x if y is None else y
