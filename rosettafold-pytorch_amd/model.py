@@ -43,6 +43,9 @@ class _Runtime:
     fused_outer = not bool(int(__import__("os").environ.get("RF_NO_FUSED_OUTER", "0")))  # outer product -> LN -> Linear in one kernel
     tied_v2 = not bool(int(__import__("os").environ.get("RF_TIED_V1", "0")))  # head-major q|k|v + collapsed weights + A.V kernel
     tied_fold_w = not bool(int(__import__("os").environ.get("RF_TIED_NO_FOLD", "0")))  # position weights folded into q by the projection's epilogue
+    # pair-track row blocks (shard.forward_row_sharded): how the attention direction that crosses the blocks is computed --
+    # "transpose" (two transposing exchanges, fused kernel) or "contexts" (all-reduce of the Performer contexts, GEMM chain)
+    rowshard_attention = __import__("os").environ.get("RF_ROWSHARD_ATTENTION", "transpose")
     head_major_qkv = int(__import__("os").environ.get("RF_HEAD_MAJOR_QKV", "0"))  # 1: every FAVOR+ layer, 2: only where the sequence is the inner row index
     # Producer -> consumer chains whose intermediate (q|k|v, feed-forward hidden) is larger than this many bytes are run
     # panel by panel, so the intermediate panel is still in the 256 MB Infinity Cache when its consumer reads it
@@ -1091,9 +1094,19 @@ class PairUpdateWithAxialAttentionLayer(RFModule):
         torch.distributed group (shard.pair_axial_layer_row_sharded): the RowWise attention all-reduces its contexts, the
         ColWise attention and the feed-forward are local."""
         l0, l1, l2 = self.layer[0].fn[0], self.layer[1].fn[0], self.layer[2].fn[0]
-        if xn is None:
-            xn = ln(l0, x)
-        xn = self.row_attn.attend(xn, x, axis=1, next_ln=l1, seq_group=row_group)
+        if row_group is not None and RT.rowshard_attention == "transpose":
+            # the direction that crosses the row blocks, on the TRANSPOSED blocks: two transposing exchanges of the fp32 stream
+            # (1/world of the tensor per rank each) instead of the all-reduce of the contexts (0.57 GB per rank at L = 1024 whatever
+            # the world size), and every sequence is whole on its rank again -- the fused FAVOR+ kernel runs as in one process
+            from . import shard
+            xt = shard.transpose_row_sharded(x, row_group)
+            self.row_attn.attend(ln(l0, xt), xt, axis=2)
+            ops.axpby(shard.transpose_row_sharded(xt, row_group), 1.0, None, 0.0, x)
+            xn = None
+        else:
+            if xn is None:
+                xn = ln(l0, x)
+            xn = self.row_attn.attend(xn, x, axis=1, next_ln=l1, seq_group=row_group)
         if xn is None:
             xn = ln(l1, x)
         xn = self.col_attn.attend(xn, x, axis=2, next_ln=l2)

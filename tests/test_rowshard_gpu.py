@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 if not torch.cuda.is_available():
     pytest.skip("needs a GPU", allow_module_level=True)
 
-D, H, L1, L2 = 96, 8, 48, 40
+D, H, L1, L2 = 96, 8, 48, 48
 CUT = 32  # rank 0: rows [0, 32), rank 1: rows [32, 48)
 
 
@@ -22,8 +22,8 @@ def _x():
     return torch.randn(1, L1, L2, D, generator=torch.Generator().manual_seed(5))
 
 
-def _worker(rank, world, port, wpath, opath, dtype):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, wpath, opath, dtype, mode="contexts", cut=None):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RF_ROWSHARD_ATTENTION=mode)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import rosettafold_pytorch_amd as R
@@ -32,7 +32,8 @@ def _worker(rank, world, port, wpath, opath, dtype):
     layer = R.PairUpdateWithAxialAttention(D, 2 * D, H, 0.0, 2)
     layer.load_state_dict(torch.load(wpath))
     layer = layer.to("cuda:0")
-    lo, hi = (0, CUT) if rank == 0 else (CUT, L1)
+    cut = CUT if cut is None else cut
+    lo, hi = (0, cut) if rank == 0 else (cut, L1)
     out = shard.pair_axial_layer_row_sharded(layer, _x()[:, lo:hi].to("cuda:0"))
     torch.cuda.synchronize()
     torch.save(out.cpu(), f"{opath}.{rank}")
@@ -40,9 +41,12 @@ def _worker(rank, world, port, wpath, opath, dtype):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode,cut", [("contexts", CUT), ("transpose", L1 // 2)])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)],
                          ids=["fp32", "bf16", "fp16"])
-def test_axial_layer_row_sharded_world2(tmp_path, dtype, tol):
+def test_axial_layer_row_sharded_world2(tmp_path, dtype, tol, mode, cut):
+    """mode "contexts": the crossing direction all-reduces its Performer contexts (any split of the rows: 32 + 16 here);
+    mode "transpose" (the default of the sharded forward): it runs on transposed blocks (the contiguous even split)."""
     import rosettafold_pytorch_amd as R
     wpath, opath = str(tmp_path / "layer.pt"), str(tmp_path / "rows.pt")
     torch.manual_seed(77)
@@ -50,7 +54,7 @@ def test_axial_layer_row_sharded_world2(tmp_path, dtype, tol):
     torch.save(layer.state_dict(), wpath)
     ctx = mp.get_context("spawn")
     port = 35500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, wpath, opath, dtype)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, wpath, opath, dtype, mode, cut)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -68,7 +72,7 @@ def test_axial_layer_row_sharded_world2(tmp_path, dtype, tol):
     st = {"m." + k: v.detach().float().cpu() for k, v in layer.state_dict().items()}
     ora = O.pair_update_with_axial_attention(st, "m", _x(), 2)
     err_o = ((got - ora).abs().max() / ora.abs().max()).item()
-    print(f"\n[row shard {dtype}] two row blocks (32 + 16 of 48): vs one process max-rel {err:.3e}, vs oracle {err_o:.3e}")
+    print(f"\n[row shard {dtype} {mode}] two row blocks ({cut} + {L1 - cut} of {L1}): vs one process max-rel {err:.3e}, vs oracle {err_o:.3e}")
     assert got.shape == ref.shape and err < tol and err_o < tol, (err, err_o)
 
 
