@@ -10,6 +10,7 @@ from .structure import flat_state  # noqa: F401
 from .model import invalidate_weight_caches  # noqa: F401
 from . import weights  # noqa: F401
 from . import featurize  # noqa: F401
+from . import shard  # noqa: F401  (batch shards / pair-track row blocks over torch.distributed ranks)
 from .graph import GraphedForward  # noqa: F401
 from .structure import check_edge_capacity  # noqa: F401
 from .weights import export_hidden_lists, load_reference_weights, save_checkpoint, load_checkpoint  # noqa: F401
