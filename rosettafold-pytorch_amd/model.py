@@ -1014,6 +1014,19 @@ class PairUpdateWithMsa(RFModule):
         x = ops.linear(feat, self.wt("f", self.resnet[0], kpad=Kf), _f(self.resnet[0].bias), out_dtype=F32)
         blk = self.resnet[1].fn
         kw = {"row_group": row_group, "rows_global": Lr}
+        if B == 1:   # one picture: pre-haloed buffers, only the halo rows move (see ResBlock2D._run_rows_b1)
+            xh = shard.haloed_buffer(h, Lr, Dp, 1, dev, T())
+            ops.axpby(x, 1.0, None, 0.0, shard.interior(xh, 1))
+            shard.exchange_row_halos_inplace(xh, 1, row_group)
+            y = conv3x3(self, "c1", blk[1], xh, 1)
+            yh = shard.haloed_buffer(h, Lr, Dp, 1, dev, T())
+            ops.instnorm(shard.interior(y, 1), _f(blk[2].weight), _f(blk[2].bias), eps=blk[2].eps, act=L.ACT_ELU,
+                         out=shard.interior(yh, 1), **kw)
+            shard.exchange_row_halos_inplace(yh, 1, row_group)
+            y = conv3x3(self, "c2", blk[5], yh, 1)
+            out, _ = ops.instnorm(shard.interior(y, 1), _f(blk[6].weight), _f(blk[6].bias), eps=blk[6].eps, residual=x,
+                                  act=L.ACT_ELU, out_dtype=F32, **kw)
+            return out
         conv = lambda key, c, t: shard.drop_row_halos(conv3x3(self, key, c, shard.exchange_row_halos(t, 1, row_group), 1), 1)  # noqa: E731
         y = conv("c1", blk[1], ops.cast(x, T()))
         y, _ = ops.instnorm(y, _f(blk[2].weight), _f(blk[2].bias), eps=blk[2].eps, act=L.ACT_ELU, out_dtype=T(), **kw)
@@ -1422,12 +1435,36 @@ class ResBlock2D(RFModule):
             nn.Conv2d(channel, channel, kernel_size, dilation=dilation, padding="same", bias=False),
             nn.InstanceNorm2d(channel, affine=True, eps=1e-6)))
 
-    def run(self, x_t, x_f, row_group=None, rows_global=None):
+    def _run_rows_b1(self, x_t, x_f, row_group, rows_global, next_halo):
+        """Row block of ONE picture (a contiguous slab): the convolutions read pre-haloed buffers whose interiors the producers
+        wrote directly -- only the halo rows move (shard.exchange_row_halos_inplace), no full-size copy."""
+        from . import shard
+        f, d = self.layer.fn, self.dilation
+        _, h, W, Cc = x_t.shape
+        kw = {"row_group": row_group, "rows_global": rows_global}
+        xh = shard.haloed_parent(x_t, d)
+        if xh is None:   # (the first block of a chain: its input was not produced into a haloed buffer)
+            xh = shard.haloed_buffer(h, W, Cc, d, x_t.device, x_t.dtype)
+            ops.axpby(x_t.contiguous(), 1.0, None, 0.0, shard.interior(xh, d))
+        shard.exchange_row_halos_inplace(xh, d, row_group)
+        y = conv3x3(self, "c1", f[0], xh, d)
+        yh = shard.haloed_buffer(h, W, y.shape[-1], d, x_t.device, T())
+        ops.instnorm(shard.interior(y, d), _f(f[1].weight), _f(f[1].bias), eps=f[1].eps, act=L.ACT_ELU, out=shard.interior(yh, d), **kw)
+        shard.exchange_row_halos_inplace(yh, d, row_group)
+        y = conv3x3(self, "c2", f[4], yh, d)
+        nxt = shard.haloed_buffer(h, W, y.shape[-1], next_halo, x_t.device, T())
+        o_f, o_t = ops.instnorm(shard.interior(y, d), _f(f[5].weight), _f(f[5].bias), eps=f[5].eps, residual=x_f, act=L.ACT_ELU,
+                                out_dtype=F32, out2=shard.interior(nxt, next_halo), **kw)
+        return o_t, o_f
+
+    def run(self, x_t, x_f, row_group=None, rows_global=None, next_halo=0):
         """x_t: T NHWC (conv input), x_f: fp32 copy (residual).  Returns (T, fp32) of elu(block(x)+x).
         row_group / rows_global: x holds a block of the picture's rows (shard.resblock_row_sharded): every convolution first
         fetches `dilation` rows from each neighbouring rank, the InstanceNorm sums are all-reduced."""
         f = self.layer.fn
         kw = {} if row_group is None else {"row_group": row_group, "rows_global": rows_global}
+        if row_group is not None and x_t.shape[0] == 1:
+            return self._run_rows_b1(x_t, x_f, row_group, rows_global, next_halo)
 
         def conv(key, c, x):
             if row_group is None:
@@ -1468,9 +1505,16 @@ class ResNet(RFModule):
         l0, l1 = self.layer[0], self.layer[1]
         kw = {} if row_group is None else {"row_group": row_group, "rows_global": rows_global}
         h = ops.linear(x_t, self.wt("in", l0), None)
-        h_f, h_t = ops.instnorm(h, _f(l1.weight), _f(l1.bias), eps=l1.eps, act=L.ACT_ELU, out_dtype=F32, out2_dtype=T(), **kw)
+        dil = [self.layer[3 + b].dilation for b in range(self.n_res_blocks)] + [0]
+        if row_group is not None and h.shape[0] == 1:
+            from . import shard
+            first = shard.haloed_buffer(h.shape[1], h.shape[2], h.shape[3], dil[0], h.device, T())
+            h_f, h_t = ops.instnorm(h, _f(l1.weight), _f(l1.bias), eps=l1.eps, act=L.ACT_ELU, out_dtype=F32,
+                                    out2=shard.interior(first, dil[0]), **kw)
+        else:
+            h_f, h_t = ops.instnorm(h, _f(l1.weight), _f(l1.bias), eps=l1.eps, act=L.ACT_ELU, out_dtype=F32, out2_dtype=T(), **kw)
         for b in range(self.n_res_blocks):
-            h_t, h_f = self.layer[3 + b].run(h_t, h_f, **kw)
+            h_t, h_f = self.layer[3 + b].run(h_t, h_f, next_halo=dil[b + 1], **kw)
         lo = self.layer[3 + self.n_res_blocks]
         return ops.linear(h_t, self.wt("out", lo), _f(lo.bias), out_dtype=F32)
 

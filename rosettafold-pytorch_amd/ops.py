@@ -346,7 +346,7 @@ def weighted_msa_sum(x, w, y, y_ld):
 
 
 def instnorm(x, gamma, beta, *, eps=1e-6, residual=None, act=L.ACT_NONE, out_dtype=None, out2_dtype=None, row_group=None,
-             rows_global=None):
+             rows_global=None, out=None, out2=None):
     """InstanceNorm2d(affine) over NHWC x [B,H,W,C]; returns (y, y2) where y2 is an optional second copy.
     row_group / rows_global: x is a block of H of the picture's rows_global rows, the other blocks live on the other ranks of
     the torch.distributed group: the per-(b, c) sums are all-reduced (2*B*C doubles) before they are applied."""
@@ -362,8 +362,13 @@ def instnorm(x, gamma, beta, *, eps=1e-6, residual=None, act=L.ACT_NONE, out_dty
         shard.all_reduce_sum(sums, row_group)
         # rf_instnorm_apply divides by ITS pixel count: hand it global sums scaled to the local block (exact up to one rounding)
         sums.mul_(float(H) / float(rows_global))
-    y = torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
-    y2 = torch.empty(x.shape, device=x.device, dtype=out2_dtype) if out2_dtype is not None else None
+    # out / out2: caller-owned contiguous destinations (e.g. the interior of a pre-haloed picture, shard.haloed_buffer)
+    y = out if out is not None else torch.empty(x.shape, device=x.device, dtype=out_dtype or x.dtype)
+    y2 = out2 if out2 is not None else (torch.empty(x.shape, device=x.device, dtype=out2_dtype) if out2_dtype is not None else None)
+    for t in (y, y2):
+        if t is not None and (tuple(t.shape) != tuple(x.shape) or not t.is_contiguous()):
+            raise ValueError("instnorm: out / out2 must be contiguous tensors of the input's shape")
+    _need_cuda(y, y2)
     check(lib.rf_instnorm_apply(ptr(x), dcode(x.dtype), ptr(sums), ptr(gamma), ptr(beta), eps, ptr(residual), act,
                                 ptr(y), dcode(y.dtype), ptr(y2), dcode(y2.dtype) if y2 is not None else 0, B, H * W,
                                 Cc, stream()), "rf_instnorm_apply")

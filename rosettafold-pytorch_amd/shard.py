@@ -340,3 +340,57 @@ def forward_row_sharded(model, msa, seq, aa_idx, group=None):
     S.check_edge_capacity()
     return out
 
+
+# ---- pre-haloed pictures (B == 1: a block of rows is one contiguous slab, so producers can write straight into the interior) ----
+def haloed_buffer(h, W, Cc, d, device, dtype):
+    """[1, h + 2 d, W, C] with the 2 d halo rows zeroed (the 'same' padding at the picture's edge; exchange_row_halos_inplace
+    overwrites the inner edges); the interior is left for the producer."""
+    from . import ops
+    xh = torch.empty(1, h + 2 * d, W, Cc, device=device, dtype=dtype)
+    if d > 0:
+        ops.fill(xh[0, :d], 0.0)
+        ops.fill(xh[0, d + h:], 0.0)
+    return xh
+
+
+def interior(xh, d):
+    return xh[:, d:xh.shape[1] - d] if d > 0 else xh
+
+
+def haloed_parent(x, d):
+    """The pre-haloed buffer x is the interior of (halo d), or None."""
+    b = x._base
+    if b is None or x.dim() != 4 or b.dim() != 4 or x.shape[0] != 1:
+        return None
+    _, h, W, Cc = x.shape
+    if tuple(b.shape) == (1, h + 2 * d, W, Cc) and x.data_ptr() == b.data_ptr() + d * W * Cc * x.element_size() and b.is_contiguous():
+        return b
+    return None
+
+
+def exchange_row_halos_inplace(xh, d, group=None):
+    """Fill the halo rows of a pre-haloed [1, h + 2 d, W, C] picture from the neighbouring ranks' edge rows (zeros stay at the
+    picture's edge).  Only the 2 d halo rows move."""
+    n, r = group_size(group), group_rank(group)
+    if n == 1 or d == 0:
+        return xh
+    h = xh.shape[1] - 2 * d
+    if h < d:
+        raise ValueError(f"row block of {h} rows is lower than the halo of {d}")
+    host = dist.get_backend(group) == "gloo"
+    ops_, recv = [], []
+    for peer, send_view, recv_view in ((r - 1, xh[0, d:2 * d], xh[0, :d]), (r + 1, xh[0, h:h + d], xh[0, d + h:])):
+        if 0 <= peer < n:
+            buf = torch.empty(recv_view.shape, device="cpu", dtype=xh.dtype) if host else recv_view
+            ops_.append(dist.P2POp(dist.isend, send_view.cpu() if host else send_view, _peer(group, peer), group))
+            ops_.append(dist.P2POp(dist.irecv, buf, _peer(group, peer), group))
+            recv.append((recv_view, buf))
+    if not host:
+        torch.cuda.current_stream().synchronize()
+    for w in dist.batch_isend_irecv(ops_):
+        w.wait()
+    if host:
+        for view, buf in recv:
+            view.copy_(buf)
+    return xh
+
