@@ -209,12 +209,12 @@ def transpose_row_sharded(x_rows, group=None):
         hs = s1 - s0
         if hs == 0 or h == 0:
             continue
+        if s_ == r:  # the diagonal block never leaves: one transposing copy  out[b, i, r0 + j] = x[b, j, r0 + i]
+            ops.copy4d(x_rows, (h * row, Cc, row, 1), out, (h * row, row, Cc, 1), (B, h, h, Cc), x_off=r0 * Cc, y_off=r0 * Cc)
+            continue
         # my rows, columns of rank s: [B, h, hs, C] contiguous
         blk = ops.copy4d(x_rows, (h * row, row, Cc, 1), torch.empty(B, h, hs, Cc, device=x_rows.device, dtype=x_rows.dtype),
                          (h * hs * Cc, hs * Cc, Cc, 1), (B, h, hs, Cc), x_off=s0 * Cc)
-        if s_ == r:
-            recv[s_] = blk
-            continue
         buf = torch.empty(B, hs, h, Cc, device="cpu" if host else x_rows.device, dtype=x_rows.dtype)  # rank s's rows, my columns
         ops_.append(dist.P2POp(dist.isend, blk.cpu() if host else blk, _peer(group, s_), group))
         ops_.append(dist.P2POp(dist.irecv, buf, _peer(group, s_), group))
