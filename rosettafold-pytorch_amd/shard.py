@@ -104,9 +104,14 @@ def forward_sharded(model, msa, seq, aa_idx, dst=0):
 # ----------------------------------------------------------------------------------------------------------------------
 # Pair-track row-block sharding, first piece: one axial-attention layer on a block of rows
 # ----------------------------------------------------------------------------------------------------------------------
+# RF_SHARD_FORCE_COLLECTIVES=1: issue the collectives even in a one-rank group (tests/test_rowshard_gpu.py runs the device
+# branches of all_reduce / all_gather through RCCL that way on the one-GPU box)
+_FORCE = bool(int(__import__("os").environ.get("RF_SHARD_FORCE_COLLECTIVES", "0")))
+
+
 def all_reduce_sum(t, group=None):
     """In-place sum over the ranks of `group` (RCCL on device tensors; the gloo rehearsal goes through the host)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _FORCE):
         return t
     if dist.get_backend(group) == "gloo" and t.is_cuda:
         h = t.cpu()
@@ -254,7 +259,7 @@ def all_gather_positions(rows, full, group=None):
     B, N, h, D = rows.shape
     Lr = full.shape[2]
     n, r = group_size(group), group_rank(group)
-    if n == 1:
+    if n == 1 and not (_FORCE and dist.is_initialized()):
         ops.copy4d(rows, (N * h * D, h * D, D, 1), full, (N * Lr * D, Lr * D, D, 1), (B, N, h, D))
         return full
     hmax = max(shard_range(Lr, n, k)[1] - shard_range(Lr, n, k)[0] for k in range(n))

@@ -516,3 +516,47 @@ def test_forward_row_sharded_benchmark_dims(tmp_path, dtype, tol):
         e_sh, e_1p = l2(got, res[torch.float32][k]), l2(res[dtype][k], res[torch.float32][k])
         print(f"\n[row shard forward {dtype}, benchmark dims] {k}: sharded vs fp32 mode rel-L2 {e_sh:.3e} (single process, same mode: {e_1p:.3e})")
         assert e_sh < tol and e_sh < 3 * e_1p + 1e-3, (k, e_sh, e_1p)
+
+
+# ---- the device branches of the collectives through RCCL (backend "nccl"), as far as one GPU allows: a one-rank group ------------
+def _nccl_worker(port, ckpt, opath):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RF_SHARD_FORCE_COLLECTIVES="1",
+                      RF_ROWSHARD_ATTENTION="contexts")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    import rosettafold_pytorch_amd as R
+    from rosettafold_pytorch_amd import shard
+    R.set_compute_dtype(torch.float32)
+    model = R.RoseTTAFold(**FCFG)
+    R.load_checkpoint(model, ckpt)
+    model = model.to("cuda:0")
+    logits, xyz, plddt = shard.forward_row_sharded(model, *_f_inputs())
+    torch.cuda.synchronize()
+    torch.save({"logits": {k: v.cpu() for k, v in logits.items()}, "xyz": xyz.cpu(), "plddt": plddt.cpu()}, opath)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_forward_row_sharded_rccl_one_rank(tmp_path):
+    """dist.all_reduce (Performer contexts, InstanceNorm sums) and dist.all_gather (msa positions, pair rows) on DEVICE tensors
+    through RCCL -- a one-rank group is all a one-GPU box can host, the collectives are forced to run anyway."""
+    import rosettafold_pytorch_amd as R
+    ckpt, opath = str(tmp_path / "model.pt"), str(tmp_path / "out.pt")
+    torch.manual_seed(83)
+    model = R.RoseTTAFold(**FCFG)
+    R.save_checkpoint(model, ckpt)
+    p = mp.get_context("spawn").Process(target=_nccl_worker, args=(51500 + os.getpid() % 2000, ckpt, opath))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    got = torch.load(opath)
+    R.set_compute_dtype(torch.float32)
+    try:
+        rl, rx, rp = model.to("cuda:0")(*[t.cuda() for t in _f_inputs()])
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    e = lambda a, b: ((a.cpu() - b.cpu()).abs().max() / b.abs().max().clamp_min(1e-20)).item()  # noqa: E731
+    errs = {k: e(got["logits"][k], rl[k]) for k in rl}
+    errs["xyz"], errs["plddt"] = e(got["xyz"], rx), e(got["plddt"], rp)
+    print("\n[row shard forward, RCCL one-rank group] vs plain forward: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert all(v < 1e-3 for v in errs.values()), errs
