@@ -7,6 +7,11 @@ the results on rank 0: one flat fp32 buffer per rank (logits | xyz | plddt), `to
 import torch
 import torch.distributed as dist
 
+# RF_SHARD_FORCE_COLLECTIVES=1: issue the collectives even in a one-rank group (tests/test_rowshard_gpu.py runs the device
+# branches of all_reduce / all_gather through RCCL that way on the one-GPU box)
+_FORCE = bool(int(__import__("os").environ.get("RF_SHARD_FORCE_COLLECTIVES", "0")))
+
+
 LOGIT_KEYS = ("theta", "phi", "dist", "omega")
 LOGIT_BINS = {"theta": 37, "phi": 19, "dist": 37, "omega": 37}
 
@@ -58,7 +63,7 @@ def gather_results(logits, xyz, plddt, dst=0, batch_sizes=None):
     """Gather every rank's results on `dst`; returns a list of (logits, xyz, plddt) on dst, None elsewhere.
     batch_sizes: per-rank batch sizes when they differ (uneven shards: every rank pads its flat buffer to the largest
     shard, `torch.distributed.gather` needs equal sizes); None = all ranks hold the same batch size (weak scaling)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not _FORCE):
         return [(logits, xyz, plddt)]
     B, L = plddt.shape
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -104,11 +109,6 @@ def forward_sharded(model, msa, seq, aa_idx, dst=0):
 # ----------------------------------------------------------------------------------------------------------------------
 # Pair-track row-block sharding, first piece: one axial-attention layer on a block of rows
 # ----------------------------------------------------------------------------------------------------------------------
-# RF_SHARD_FORCE_COLLECTIVES=1: issue the collectives even in a one-rank group (tests/test_rowshard_gpu.py runs the device
-# branches of all_reduce / all_gather through RCCL that way on the one-GPU box)
-_FORCE = bool(int(__import__("os").environ.get("RF_SHARD_FORCE_COLLECTIVES", "0")))
-
-
 def all_reduce_sum(t, group=None):
     """In-place sum over the ranks of `group` (RCCL on device tensors; the gloo rehearsal goes through the host)."""
     if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not _FORCE):

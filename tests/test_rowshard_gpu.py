@@ -532,6 +532,11 @@ def _nccl_worker(port, ckpt, opath):
     model = model.to("cuda:0")
     logits, xyz, plddt = shard.forward_row_sharded(model, *_f_inputs())
     torch.cuda.synchronize()
+    # ... and the one collective of the batch-sharded bench path (bench.py step(): shard.gather_results -> dist.gather on the
+    # flat device buffer packed by rf_axpby), also forced through RCCL
+    plain = model(*[t.cuda() for t in _f_inputs()])
+    (gl, gx, gp), = shard.gather_results(*plain, dst=0)
+    assert all(torch.equal(gl[k], plain[0][k]) for k in gl) and torch.equal(gx, plain[1]) and torch.equal(gp, plain[2])
     torch.save({"logits": {k: v.cpu() for k, v in logits.items()}, "xyz": xyz.cpu(), "plddt": plddt.cpu()}, opath)
     dist.barrier()
     dist.destroy_process_group()
