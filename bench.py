@@ -303,6 +303,9 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) | gloo (rehearsal on a 1-GPU box)")
     ap.add_argument("--no-graph", action="store_true", help="issue the forward's launches eagerly instead of replaying one hipGraph")
+    ap.add_argument("--rehearse-dist", action="store_true",
+                    help="one-GPU rehearsal of the multi-GPU code path: with WORLD_SIZE=1 still create the process group and run the "
+                         "barrier / gather / all-reduce of every step through it (RCCL one-rank group; collectives forced)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -311,7 +314,11 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)  # before the process group: RCCL binds its communicator to the current device
     dev = torch.device("cuda", local)
-    if world > 1:
+    dist_on = world > 1 or args.rehearse_dist
+    if args.rehearse_dist:
+        os.environ["RF_SHARD_FORCE_COLLECTIVES"] = "1"  # (read when rosettafold_pytorch_amd.shard is imported, below)
+        os.environ.setdefault("MASTER_PORT", "29741")
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
@@ -345,13 +352,13 @@ def main():
 
     def step():
         out = run()
-        if world > 1 and args.config != 5:  # the one collective of the path: gather the results on rank 0 (RCCL over xGMI)
+        if dist_on and args.config != 5:  # the one collective of the path: gather the results on rank 0 (RCCL over xGMI)
             from rosettafold_pytorch_amd import shard
             shard.gather_results(out[0], out[1], out[2], dst=0)
         return out
 
     def fence():
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -369,7 +376,7 @@ def main():
     dt = time.perf_counter() - t0
     if rank == 0:
         log(f"{args.steps} timed steps: {dt:.3f}s")
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         tt = torch.tensor([dt], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -439,7 +446,7 @@ def main():
         if world == 1 and full and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
 
