@@ -317,7 +317,11 @@ def test_blocks(mode):
     if fp32:  # the bf16 path crosses the structure module's discontinuities (test_coord_update): robust bound only
         assert rel(m3, rm) < 5e-4 and rel(p3, rp) < 5e-4 and rel(x3, rx) < 5e-4
     else:
-        assert rel2(m3, rm) < 0.1 and rel2(p3, rp) < 0.05 and rel2(x3, rx) < 0.3
+        print(f"\n[blocks {mode[0]}] three-track rel-L2: msa {rel2(m3, rm):.2e} pair {rel2(p3, rp):.2e} xyz {rel2(x3, rx):.2e}")
+        # 16-bit modes: the two tracks carry operand rounding, the structure track is fp32 on fp32 inputs (round 3); observed
+        # bf16 5e-3 / 5e-3 / 2e-4, fp16 5e-4 / 7e-4 / 3e-5 -- bounds at ~5x (round 2 needed 0.1 / 0.05 / 0.3)
+        t = 3e-2 if mode[0] == torch.bfloat16 else 4e-3
+        assert rel2(m3, rm) < t and rel2(p3, rp) < t and rel2(x3, rx) < t / 10
     fin = build(lambda: R.FinalBlock(DM, DP, DN, DE, DS, 1, 0.0))
     m4, p4, x4, pl = fin(msa.to(DEV), pair.to(DEV), xyz.to(DEV), onehot.to(DEV), AA.to(DEV))
     rm, rp, rx, rpl = O.three_track_block(state(fin), "m", msa, pair, xyz, onehot, AA, 1, 32, DS, final=True)
@@ -325,7 +329,8 @@ def test_blocks(mode):
     if fp32:
         assert rel(m4, rm) < 5e-4 and rel(p4, rp) < 5e-4 and rel(x4, rx) < 5e-4 and rel(pl, rpl) < 5e-4
     else:
-        assert rel2(p4, rp) < 0.05 and rel2(x4, rx) < 0.3 and rel2(pl, rpl) < 0.3
+        print(f"[blocks {mode[0]}] final rel-L2: pair {rel2(p4, rp):.2e} xyz {rel2(x4, rx):.2e} plddt {rel2(pl, rpl):.2e}")
+        assert rel2(p4, rp) < t and rel2(x4, rx) < t / 10 and rel2(pl, rpl) < t
 
 
 def test_full_model_shapes_and_parity(mode):
@@ -340,10 +345,14 @@ def test_full_model_shapes_and_parity(mode):
         assert all(e[0] < 5e-4 for e in errs.values()), errs
         assert agree == 1.0
     else:
-        # bf16 MFMA path with a three-track block in the stack: the structure module's discontinuities
-        # (test_coord_update) feed back into msa/pair, so only a robust bound holds at random init
-        assert all(e[1] < 0.3 for e in errs.values()), errs
-        assert agree > 0.75
+        # 16-bit operand paths at random init: the flat random-init distogram amplifies the pair-stream rounding (DESIGN.md
+        # section 4); observed rel-L2 bf16 0.12 (logits) / 0.03 (xyz, plddt), argmax 0.88; fp16 3e-3, argmax > 0.99
+        if mode[0] == torch.bfloat16:
+            assert all(e[1] < 0.25 for e in errs.values()), errs
+            assert agree > 0.8
+        else:
+            assert all(e[1] < 2e-2 for e in errs.values()), errs
+            assert agree > 0.95
 
 
 def test_full_model_smooth_path_bf16_tolerance(mode):
