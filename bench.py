@@ -291,12 +291,32 @@ def se3_inputs(cfg, dev, seed):
     return [t.to(dev) for t in (xyz, msa, pair, aa, oh)]
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a CHILD process (never an exec: this process
+    may not be replaced once a GPU library is loaded) and return its exit code.  The children's stdout (rank 0's one JSON
+    line) and stderr pass straight through."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__), *argv]
+    log("starting %d ranks: %s" % (n, " ".join(cmd)))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -306,11 +326,36 @@ def main():
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="one-GPU rehearsal of the multi-GPU code path: with WORLD_SIZE=1 still create the process group and run the "
                          "barrier / gather / all-reduce of every step through it (RCCL one-rank group; collectives forced)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only (gloo, no GPU call): every rank joins the group, rank 0 prints {n_gpus, ranks_seen}; "
+                         "the CPU test of the --gpus N launcher (tests/test_bench_launcher.py)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: nothing has touched the GPU yet, so start the N ranks as a child job (one process
+        # per GPU, torch.distributed.run -> RCCL), relay rank 0's JSON line and leave with the child's exit code
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        ap.error(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or unset WORLD_SIZE and "
+                 f"let bench.py start the ranks itself)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29743")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = torch.zeros(world, dtype=torch.int64)
+        seen[rank] = 1
+        dist.all_reduce(seen)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_seen": int(seen.sum()), "local_rank": local}), flush=True)
+        dist.destroy_process_group()
+        return
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)  # before the process group: RCCL binds its communicator to the current device
     dev = torch.device("cuda", local)

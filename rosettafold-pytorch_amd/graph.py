@@ -12,9 +12,10 @@ Replays are bitwise equal to the eager forward.
 
 The returned tensors are the graph's static outputs: they are overwritten by the next call (clone what must survive).
 Validation (token / residue-index range -> IndexError, as the reference's nn.Embedding raises) runs before every replay,
-outside the graph: it needs a 12-byte read-back.  A change of weights needs a new capture only if parameter STORAGE
-changes (load_state_dict copies in place: the prepared 16-bit weight copies are keyed on parameter versions and are
-rebuilt by an eager forward, so call `recapture()` after loading weights).
+outside the graph: it needs a 12-byte read-back.  The graph's kernels read the prepared 16-bit weight copies by raw
+pointer, so every call compares the parameters' fingerprint (model.weights_fingerprint: one pass over the parameter list,
+what the public forward does as well) with the one of the capture and records a new graph when load_state_dict /
+load_checkpoint / .to() / an in-place parameter edit / invalidate_weight_caches happened in between.
 """
 import torch
 
@@ -42,6 +43,14 @@ class GraphedForward:
         """(Re)record the graph: after load_state_dict / set_compute_dtype, or for the other residue-index branch."""
         with torch.cuda.device(self.device), torch.no_grad():
             self._dtype = M.T()   # the graph holds the kernels of the library active now
+            # the recorded kernels read the prepared 16-bit weight copies by raw pointer: bring the copies in line with the live
+            # parameters first (what the public model(...) call does), and remember which parameters the graph belongs to
+            fp = M.weights_fingerprint(self.model)
+            if fp != self.model._rf_fp:
+                M.invalidate_weight_caches(self.model)
+                object.__setattr__(self.model, "_rf_fp", fp)
+            self._fp = fp
+            self._epoch = M.RT.cache_epoch
             self._mono = self._validate(*self._in) if monotonic is None else monotonic
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -69,7 +78,10 @@ class GraphedForward:
         with torch.cuda.device(self.device):
             msa, seq, aa_idx = msa.contiguous(), seq.contiguous(), aa_idx.contiguous()
             mono = self._validate(msa, seq, aa_idx)   # IndexError before anything is overwritten
-            if mono != self._mono:                    # the structure track takes another branch for unordered residue indices
+            # weights changed since the capture (load_state_dict / load_checkpoint / .to() / p.copy_ / invalidate_weight_caches):
+            # the graph's kernels point at weight copies that were freed or are stale -> record a new graph
+            stale = M.weights_fingerprint(self.model) != self._fp or M.RT.cache_epoch != self._epoch
+            if mono != self._mono or stale:                    # the structure track takes another branch for unordered residue indices
                 for new, static in zip((msa, seq, aa_idx), self._in):
                     static.copy_(new)
                 self.recapture(monotonic=mono)

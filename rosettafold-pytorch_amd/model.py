@@ -33,6 +33,7 @@ VT_ROWS = 80   # 64 value rows + the ones row (k' sums) padded to a multiple of 
 
 class _Runtime:
     dtype = torch.bfloat16
+    cache_epoch = 0  # bumped whenever kernel-ready weight copies are dropped (graph.GraphedForward re-records on a change)
     # structure-track node input (LayerNorm(msa) -> position-weighted sum, rf.py:789-798) in fp32 also in the 16-bit modes:
     # the SE(3) stack is discontinuous (GNormBias, kNN, distance bins), so its inputs are not the place to round
     # (tools/depth_parity.py --struct-lowp measures the difference)
@@ -107,6 +108,7 @@ def weights_fingerprint(module):
 
 def invalidate_weight_caches(module):
     """Drop every kernel-ready weight copy held below `module` (they are rebuilt on the next call)."""
+    RT.cache_epoch += 1
     for m in module.modules():
         c = getattr(m, "_rfc", None)
         if isinstance(c, dict):
@@ -131,6 +133,7 @@ class RFModule(nn.Module):
 
     def _load_from_state_dict(self, *a, **k):
         self._rfc.clear()
+        RT.cache_epoch += 1
         return super()._load_from_state_dict(*a, **k)
 
     def __call__(self, *a, **k):
@@ -487,8 +490,8 @@ class SoftTiedAttentionOverResidues(RFModule):
                 and (6 if Lr >= 256 else 8) * (4096 + Lr * 64) + 1024 + N * 256 <= 160 * 1024):
             return self.attend_head_major(xn, x_res, want_att, next_ln)
         if (RT.fused_tied and RT.tied_v2 and RT.tied_fold_w and ops.is_h16(T()) and dh == 32 and Lr in (512, 768, 1024) and H <= 16
-                and D in (288, 384) and N % 16 == 0 and N // 16 in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16) and (B * N * Lr) % 256 == 0
-                and B * N * Lr >= 16384):
+                and ops.gemm_takes_row_scale(B * N * Lr, 2 * D, D) and N % 16 == 0 and N // 16 in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16)
+                and (B * N * Lr) % 256 == 0 and B * N * Lr >= 16384):
             return self.attend_long_rows(xn, x_res, want_att, next_ln)
         # one GEMM for q | k | poswise-k  (N = 3D)
         wcat = self.wcat("qkp", [self.to_q, self.to_k, pw.to_k[0]])
@@ -545,7 +548,8 @@ class SoftTiedAttentionOverResidues(RFModule):
         qkv = torch.empty(B, N, G, Lr, dh, device=dev, dtype=T())
         # q * w * d_head^-0.5 (rf.py:252) in the projection's epilogue, on the fp32 accumulators: q is rounded once, after
         # the scaling, and the logits kernel neither stages the weights nor rescales its fragments (round 2: 15-20 us of VALU)
-        fold = RT.tied_fold_w and D in (288, 384) and dh % 16 == 0
+        # ... when the projection runs on the kernel whose epilogue knows the row-group scale (d_msa = 288: N = 864 does not)
+        fold = RT.tied_fold_w and dh % 16 == 0 and ops.gemm_takes_row_scale(B * N * Lr, 3 * D, D)
         ops.gemm(xn, self.wcat("qkv", lins), qkv, B * N * Lr, 3 * D, D, bias=self.bcat("qkv", lins),
                  c_row=(Lr, G * Lr * dh, dh), c_col=(dh, Lr * dh),
                  rs=(w, H * N * Lr, N * Lr, dh, D, self.scale) if fold else None)
@@ -741,9 +745,16 @@ class PerformerSelfAttention(RFModule):
                  b_bs=(RB * D, so * D, 0), b_row=(0, 0, ss * D),
                  c_bs=(Lo * H * VT_ROWS * Ls, H * VT_ROWS * Ls, 0), c_row=(dh, VT_ROWS * Ls, Ls))
         # context^T [S,80,M_PAD] = v^T k'
+        # fp16 operands (range 65504): the context is a sum over the whole sequence, so it is stored scaled by 2^-ceil(log2 Ls_total)
+        # (on the fp32 accumulators, before the rounding) exactly as csrc/favor.hip does in the fused kernel; numerator and
+        # denominator of the final ratio carry the same power of two, the result is unchanged
+        ctx_scale = 1.0
+        if T() == torch.float16:
+            from . import shard as _shard
+            ctx_scale = 2.0 ** -math.ceil(math.log2(max(Ls * (_shard.group_size(seq_group) if seq_group is not None else 1), 1)))
         ctx = torch.empty(S, VT_ROWS, M_PAD, device=dev, dtype=T() if seq_group is None else F32)
         ops.gemm(vt, kt, ctx, VT_ROWS, M_PAD, Ls, batch=(S, 1, 1), a_bs=(VT_ROWS * Ls, 0, 0),
-                 b_bs=(M_PAD * Ls, 0, 0), c_bs=(VT_ROWS * M_PAD, 0, 0))
+                 b_bs=(M_PAD * Ls, 0, 0), c_bs=(VT_ROWS * M_PAD, 0, 0), alpha=ctx_scale)
         if seq_group is not None:
             # the one exchange of a sequence-sharded layer: [B * Lo * H, 80, 288] fp32 partial contexts (+ k' sums in row 64)
             from . import shard

@@ -139,6 +139,16 @@ def _peer(group, r):
     return r if group is None or group is dist.group.WORLD else dist.get_global_rank(group, r)
 
 
+def check_row_split(L_rows, world, halo):
+    """Every rank evaluates the SAME condition from (L, world) alone -- the lowest block of shard_range(L, world, .) is
+    L // world rows -- so an unusable split raises on every rank before anyone posts a send or a receive (a rank-local
+    `h < d` check leaves the peers blocked in RCCL while one rank raises)."""
+    min_h = L_rows // max(world, 1)
+    if world > 1 and min_h < max(halo, 1):
+        raise ValueError(f"{L_rows} picture rows over {world} ranks leave a block of {min_h} rows: lower than the halo of {halo} "
+                         f"rows the dilated 3x3 convolutions exchange with ONE neighbour (use fewer ranks)")
+
+
 def exchange_row_halos(x, d, group=None):
     """x: [B, h, W, C] contiguous block of picture rows on this rank (the ranks of `group` hold consecutive blocks in rank
     order).  Returns [B, h + 2 d, W, C]: the block with d rows of each neighbour attached (zeros beyond the picture: the 'same'
@@ -146,10 +156,11 @@ def exchange_row_halos(x, d, group=None):
     device buffers; the gloo rehearsal stages through the host); slicing and placement by rf_copy4d."""
     from . import ops
     B, h, W, Cc = x.shape
-    if h < d:
-        raise ValueError(f"row block of {h} rows is lower than the halo of {d}: halos would span more than one neighbour")
     n = dist.get_world_size(group) if dist.is_initialized() else 1
     r = dist.get_rank(group) if dist.is_initialized() else 0
+    check_row_split(W, n, d)  # (square pictures: W = the number of rows of the whole picture) -- the same verdict on every rank
+    if h < d:
+        raise ValueError(f"row block of {h} rows is lower than the halo of {d}: halos would span more than one neighbour")
     row = W * Cc
     xh = ops.zeros(B, h + 2 * d, W, Cc, device=x.device, dtype=x.dtype)
     ops.copy4d(x, (h * row, row, Cc, 1), xh, ((h + 2 * d) * row, row, Cc, 1), (B, h, W, Cc), y_off=d * row)
@@ -340,6 +351,9 @@ def forward_row_sharded(model, msa, seq, aa_idx, group=None):
     msa, seq, aa_idx = msa.to(dev).contiguous(), seq.to(dev).contiguous(), aa_idx.to(dev).contiguous()
     mono = M.check_index_range(msa, seq, aa_idx, model.msa_emb.to_embedding.num_embeddings,
                                min(model.msa_emb.pos_enc.max_len, model.pair_emb.pos_enc.max_len))
+    # the widest halo of the forward: dilation 8 in the prediction head's ResNets (resnet.py:47-83); decided from (L, world) alone,
+    # identically on every rank, before the first exchange
+    check_row_split(msa.shape[2], group_size(g), 8)
     with torch.no_grad():
         out = model.forward_validated(msa, seq, aa_idx, mono, row_group=g)
     S.check_edge_capacity()
@@ -380,6 +394,7 @@ def exchange_row_halos_inplace(xh, d, group=None):
     if n == 1 or d == 0:
         return xh
     h = xh.shape[1] - 2 * d
+    check_row_split(xh.shape[2], n, d)  # collective verdict first (see check_row_split)
     if h < d:
         raise ValueError(f"row block of {h} rows is lower than the halo of {d}")
     host = dist.get_backend(group) == "gloo"

@@ -13,7 +13,7 @@ from .ops import F32
 from .model import (RFModule, Residual, FeedForward, PositionWiseWeightFactor, MsaEmbedding, PairEmbedding,
                     MsaUpdateUsingSelfAttention, PairUpdateWithMsa, PairUpdateWithAxialAttention, MsaUpdateWithPair,
                     InitialCoordGenerationWithMsaAndPair, PredictionHead, LayerNorm, Linear, _node_input, _f, ln, T, pad8,
-                    CA_IDX, fresh_f32, check_index_range)
+                    CA_IDX, fresh_f32, check_index_range, RT)
 
 
 # ================================================================================================
@@ -176,10 +176,12 @@ class GSE3Res(nn.Module):
 
     def _apply(self, fn, *a, **k):
         object.__setattr__(self, "_rfc", None)
+        RT.cache_epoch += 1
         return super()._apply(fn, *a, **k)
 
     def _load_from_state_dict(self, *a, **k):
         object.__setattr__(self, "_rfc", None)  # packed radial weights are rebuilt from the loaded parameters
+        RT.cache_epoch += 1
         return super()._load_from_state_dict(*a, **k)
 
     def run(self, h, g):

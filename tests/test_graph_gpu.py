@@ -65,3 +65,35 @@ def test_graph_keeps_the_boundary_checks():
     aa[:, 10] = 5
     ref = [t.clone() for t in flat(model(a[0], a[1], aa))]
     assert all(torch.equal(x, y) for x, y in zip(flat(g(a[0], a[1], aa)), ref))
+
+
+@pytest.mark.parametrize("how", ["load_state_dict", "copy_", "invalidate", "to"])
+def test_graph_follows_weight_changes(how):
+    """The recorded kernels read the prepared 16-bit weight copies by raw pointer; any route that drops or outdates those
+    copies must be followed by a new capture, not by a replay of freed / stale memory (round-3 advisor finding)."""
+    torch.manual_seed(11)
+    model = R.RoseTTAFold(**CFG).to(DEV)
+    a = inputs(0)
+    g = R.GraphedForward(model, *a)
+    before = [t.clone() for t in flat(g(*a))]
+    torch.manual_seed(12)
+    other = R.RoseTTAFold(**CFG).to(DEV)
+    if how == "load_state_dict":
+        model.load_state_dict(other.state_dict())
+    elif how == "copy_":
+        with torch.no_grad():
+            for p, q in zip(model.parameters(), other.parameters()):
+                p.copy_(q)
+    elif how == "invalidate":   # same weights, copies dropped: the replay must not touch the freed copies
+        R.invalidate_weight_caches(model)
+        junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(64)]   # re-use the freed blocks
+        del junk
+    else:
+        model.to(torch.float64).to(torch.float32)
+    got = [t.clone() for t in flat(g(*a))]
+    want = flat(model(*a))
+    assert all(torch.equal(x, y) for x, y in zip(got, want))
+    if how in ("load_state_dict", "copy_"):
+        assert not all(torch.equal(x, y) for x, y in zip(got, before))
+    else:
+        assert all(torch.isfinite(x).all() for x in got)
