@@ -246,6 +246,7 @@ int rf_weighted_msa_sum(const void* x, int dtype, const float* w, float* y, int6
 int64_t rf_instnorm_ws_bytes(int B, int64_t HW, int C);
 int rf_instnorm_stats(const void* x, int x_dtype, void* sums /* 2*B*C doubles */, int B, int64_t HW, int C, void* workspace,
                       int64_t ws_bytes, void* stream);
+/* gamma == beta == NULL: centre only, y = x - mean over the picture (no scaling; PredictionHead operand conditioning). */
 int rf_instnorm_apply(const void* x, int x_dtype, const void* sums, const float* gamma, const float* beta, float eps,
                       const float* residual, int act, void* y, int y_dtype, void* y2, int y2_dtype, int B, int64_t HW,
                       int C, void* stream);
@@ -365,6 +366,18 @@ int rf_se3_edge_geometry(const float* xyz, const float* edge_emb, const int32_t*
 int rf_se3_message(const float* R0, const float* R1, const float* basis, const float* h0, const float* h1,
                    const int32_t* src, const int32_t* count, float* msg, int mo, int dout, int mi0, int mi1,
                    int64_t capacity, void* stream);
+
+/* Fused form (round 4): the whole radial MLP (RadialFunc, ea/modules.py:246-284: Linear(d_edge+1 -> 32) -> LayerNorm
+ * -> ReLU -> Linear(32 -> 32) -> LayerNorm -> ReLU -> Linear(32 -> mo*mi*nf)) evaluated per edge inside the message kernel from
+ * feat [E, feat_ld] (= [edge embedding | r], ki = d_edge + 1 columns): neither the hidden vectors nor the radial outputs R
+ * are written.  net_di: the packed fp32 parameters of net (di, dout), 16-byte aligned,
+ *   [W1^T: ki x 32][b1 32][ln1 gamma 32][ln1 beta 32][W2^T: 32 x 32][b2 32][ln2 gamma 32][ln2 beta 32][W3: rows x 32][b3: rows],
+ * rows = mo*mi_di*nf_di ordered (o, i, f) as the reference's view(-1, mo, 1, mi, 1, nf) (ea/modules.py:283); mi_di = 0 / NULL:
+ * input degree absent.  rf_se3_radial_message_supported tells whether a shape has an instance (else: rf_gemm + rf_se3_message). */
+int rf_se3_radial_message_supported(int mo, int dout, int mi0, int mi1, int ki);
+int rf_se3_radial_message(const float* feat, int64_t feat_ld, int ki, const float* net0, const float* net1, const float* basis,
+                          const float* h0, const float* h1, const int32_t* src, const int32_t* count, float* msg, int mo,
+                          int dout, int mi0, int mi1, float ln_eps, int64_t capacity, void* stream);
 
 /* Graph attention (ea/modules.py:738-774): e = <k_edge, q[dst]>/sqrt(nfeat) per head, softmax over incoming edges
  * of each dst node, out[dst] = sum a * v.  k/v per-edge: k0 [E,mk0] k1 [E,mk1,3] v0 [E,mv0] v1 [E,mv1,3]; q per node.

@@ -75,6 +75,8 @@ PROTOTYPES = {
     "rf_edges_from_mask": [vp, vp, vp, vp, vp, vp, i32, i32, i64, vp],
     "rf_se3_edge_geometry": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i64, vp],
     "rf_se3_message": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, vp],
+    "rf_se3_radial_message_supported": [i32, i32, i32, i32, i32],
+    "rf_se3_radial_message": [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i64, vp],
     "rf_se3_attention": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, vp],
     "rf_se3_norm_bias": [vp, vp, vp, i64, i32, i32, vp],
     "rf_se3_gram": [vp, vp, i64, i32, i32, vp],

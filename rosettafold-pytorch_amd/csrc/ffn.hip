@@ -36,6 +36,17 @@
 #ifndef FFN_ABL
 #define FFN_ABL 0
 #endif
+// Half-step stagger (round 4, default on; -DFFN_STAGGER=0 builds the lock-step form for A/B timing).  The two waves of a SIMD
+// used to be the two column halves of ONE token group: same phase, same barrier, their LDS bursts, DMA issue and MFMA clusters
+// coincide (the guide's "two waves per SIMD in lock-step" pattern).  Now a token group is a pair of NEIGHBOURING waves (w, w ^ 1:
+// different SIMDs), waves 0-3 own groups 0-1, waves 4-7 groups 2-3, and waves 4-7 run ONE ring step behind waves 0-3: while
+// a SIMD's early wave is in step A (24 KB of W1 fragments, 24 MFMAs, pack + exchange) its late partner is in step B of the
+// previous chunk (12 KB of W2 fragments, 24 MFMAs), and the late wave's last step B overlaps the early wave's epilogue (the
+// HBM burst the matrix pipe used to sit out).  One s_barrier per ring step as before; a slot is recycled one step later (ring
+// distance NSTG - 2), the LayerNorm row statistics of a token group are exchanged through LDS flags instead of barriers.
+#ifndef FFN_STAGGER
+#define FFN_STAGGER 1
+#endif
 
 struct FfnP {
   const h16_t* X;   // [M, D] LayerNormed input (ldx elements between rows)
@@ -119,17 +130,25 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
   constexpr int PD = (PIECES + 7) / 8;        // DMA instructions per wave and slot (padded with dummies: uniform count)
   constexpr int DUMP = NSTG * SLOT;
   constexpr int XB_OFF = DUMP + 1024;         // 8 x 1 KB: lane-for-lane exchange between the two waves of a token group
-  constexpr int B1_OFF = XB_OFF + 8192;
+  constexpr int FLAG_OFF = XB_OFF + 8192;     // 8 words: sequence flags of the epilogue's pair exchange (stagger form)
+  constexpr int B1_OFF = FLAG_OFF + 64;
+  constexpr bool STG = FFN_STAGGER != 0;
+  constexpr int DIST = STG ? NSTG - 2 : NSTG - 1;  // ring steps between the issue of a slot's DMAs and its first consumer
   constexpr int PFA = 6, PFB = 4;             // fragment reads in flight ahead of the MFMAs that use them (steps A / B)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = wave & 3, ch = wave >> 2;     // token group, column half (= hidden tile of the chunk in step A)
+  // token group, column half (= token tile in step A).  Stagger form: the pair (w, w ^ 1) is a group -- two SIMDs -- and the
+  // SIMD partners w, w + 4 are different groups, the second one ring step behind the first
+  const int g = STG ? wave >> 1 : wave & 3, ch = STG ? wave & 1 : wave >> 2;
+  const int pw = STG ? wave ^ 1 : wave ^ 4;   // the other wave of this token group
+  const bool late = STG && wave >= 4;
   const int fr = lane & 15, fq = lane >> 4;
   constexpr int CPIECES = (3 * D * 4 + 1023) / 1024;  // constants slot: b2 | gamma | beta (fp32)
   constexpr int S1 = 2 * NTH;                 // posted stores per wave and tile (fp32 rows); twice that with the LayerNorm copy
 
   for (int i = tid; i < p.nchunks * 32; i += 512) ((float*)(smem + B1_OFF))[i] = p.b1[i];
+  if (tid < 16) ((unsigned*)(smem + FLAG_OFF))[tid] = 0u;
   __syncthreads();  // (before any DMA is in flight)
 
   // ---- producer side: the ring walks the stream
@@ -210,12 +229,12 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
   // steps after an epilogue those sit between the DMAs already issued and the DMA being waited for and may stay in flight: the
   // count grows by their number (capped at the 6-bit counter's 63, which only waits for a few of the oldest stores);
   // from then on the standard count has them retired.
-  constexpr int WAIT0 = PD * (NSTG - 2);
+  constexpr int WAIT0 = PD * (DIST - 1);
   constexpr int WAITF = WAIT0 + S1;                                 // first tile: + the residual loads
   constexpr int WAIT1 = WAIT0 + 2 * S1 < 63 ? WAIT0 + 2 * S1 : 63;  // + stores (fp32 rows) + residual loads (as many)
   constexpr int WAIT2 = WAIT0 + 3 * S1 < 63 ? WAIT0 + 3 * S1 : 63;  // + the LayerNorm copy's stores
-  int c_slot = 0;
-  int post = NSTG - 1;  // steps left whose DMAs were issued before this tile's residual loads (and the last epilogue's stores)
+  int c_slot = late ? NSTG - 1 : 0;  // (a late wave's dummy first step moves it to slot 0)
+  int post = DIST;  // steps left whose DMAs were issued before this tile's residual loads (and the last epilogue's stores)
   bool first = true;
   auto step = [&]() -> unsigned {
     if (post > 0) {
@@ -239,15 +258,40 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
     if (++c_slot == NSTG) c_slot = 0;
     return st;
   };
-  const unsigned xb_own = (unsigned)(XB_OFF + wave * 1024 + lane * 16), xb_oth = (unsigned)(XB_OFF + (wave ^ 4) * 1024 + lane * 16);
+  const unsigned xb_own = (unsigned)(XB_OFF + wave * 1024 + lane * 16), xb_oth = (unsigned)(XB_OFF + pw * 1024 + lane * 16);
+  // pair exchange of the epilogue without a workgroup barrier (the halves of the workgroup are in different ring steps there):
+  // publish = data write, then the flag write (a wave's LDS operations complete in order); acquire = spin on the partner's flag
+  const unsigned fl_own = (unsigned)(FLAG_OFF + wave * 4), fl_oth = (unsigned)(FLAG_OFF + pw * 4);
+  unsigned fl_seq = 0;
+  auto pair_publish = [&]() {
+    ++fl_seq;
+    asm volatile("ds_write_b32 %0, %1" ::"v"(fl_own), "v"(fl_seq) : "memory");
+  };
+  auto pair_acquire = [&]() {
+    unsigned v;
+    do {
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(fl_oth) : "memory");
+    } while ((unsigned)__builtin_amdgcn_readfirstlane((int)v) < fl_seq);  // (the partner may already have published its next one)
+  };
   const unsigned b1_rd = (unsigned)(B1_OFF + fq * 16);  // + 128 c: b1[32 c + 4 fq ..], + 64: the second hidden tile
   const int col0 = ch * (NTH * 16) + 4 * fq;
 
 #pragma unroll 1
-  for (int s = 0; s < NSTG - 1; ++s) {
+  for (int s = 0; s < DIST; ++s) {
     prep();
     dma_all();
   }
+  // one ring step without consumption: barrier + this wave's share of the step's DMAs.  Late waves take it first, early waves
+  // last, so every wave of the workgroup executes the same number of barriers
+  auto idle_step = [&]() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT0) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    prep();
+    if (++c_slot == NSTG) c_slot = 0;
+    dma_all();
+  };
+  if (late) idle_step();
 
   for (int it = 0;; ++it) {
     const int tile = blockIdx.x + it * gridDim.x;
@@ -384,8 +428,13 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
     }
     if (p.ln) {
       ffn_lds_write8(xb_own, sm[0], sm[1]);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if constexpr (STG) {
+        pair_publish();
+        pair_acquire();
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
       const ffn_u32x2 o1 = ffn_lds_read8(xb_oth);
       const float mean[2] = {(sm[0] + __uint_as_float(o1.x)) * (1.f / D), (sm[1] + __uint_as_float(o1.y)) * (1.f / D)};
 #pragma unroll
@@ -401,8 +450,13 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
         sq[tt] = q;
       }
       ffn_lds_write8(xb_own + 8, sq[0], sq[1]);   // (the other 8 bytes of the lane's 16-byte cell: the partner may still be reading the first)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if constexpr (STG) {
+        pair_publish();
+        pair_acquire();
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
       const ffn_u32x2 o2 = ffn_lds_read8(xb_oth + 8);
       float rstd[2];
 #pragma unroll
@@ -434,10 +488,11 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
         }
       }
     }
-    post = NSTG - 1;
+    post = DIST;
     first = false;
     FFN_T(6)
   }
+  if (STG && !late) idle_step();  // the late half's last ring step (the constants slot of its epilogue)
 #ifdef FFN_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7))
@@ -450,7 +505,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
 template <int D>
 static int launch_ffn(FfnP& p, int64_t M, hipStream_t s) {
   constexpr int NSTG = (144 * 1024) / (D / 16 * 1024);
-  const size_t lds = (size_t)NSTG * (D / 16 * 1024) + 1024 + 8192 + (size_t)p.nchunks * 128;
+  const size_t lds = (size_t)NSTG * (D / 16 * 1024) + 1024 + 8192 + 64 + (size_t)p.nchunks * 128;
   if (lds > 160 * 1024) return RF_EINVAL;
   const int ncu = rf_num_cus();
   if (ncu <= 0) return RF_EINVAL;

@@ -843,8 +843,8 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const void* x, int 
     const double mean = s / (double)HW;
     double var = q / (double)HW - mean * mean;
     var = var > 0.0 ? var : 0.0;
-    const float rstd = rsqrtf((float)var + eps);
-    float v = (ld(x, x_dt, e) - (float)mean) * rstd * gamma[c] + beta[c];
+    // gamma == nullptr: centre only (y = x - mean over the picture; PredictionHead's operand conditioning, model.py)
+    float v = gamma ? (ld(x, x_dt, e) - (float)mean) * rsqrtf((float)var + eps) * gamma[c] + beta[c] : ld(x, x_dt, e) - (float)mean;
     if (residual) v += residual[e];
     if (act == RF_ACT_ELU) v = elu1(v);
     st(y, y_dt, e, v);
@@ -858,7 +858,8 @@ extern "C" int rf_instnorm_apply(const void* x, int x_dtype, const void* sums, c
   RF_CHECK_DT(x_dtype);
   RF_CHECK_DT(y_dtype);
   const int64_t total = (int64_t)B * HW * C;
-  if (x_dtype == RF_H16 && C % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
+  if (!gamma != !beta) return RF_EINVAL;  // both (InstanceNorm with affine) or neither (centre only: generic kernel)
+  if (gamma && x_dtype == RF_H16 && C % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 &&
       (!y2 || ((uintptr_t)y2 % 16) == 0) && (!residual || ((uintptr_t)residual % 16) == 0)) {
     unsigned gx = min(cdiv(HW * (C / 8), 256), 4096u);
     {  // grid stride (gx * 256 chunks) a multiple of the C / 8 chunks of a pixel: every thread keeps one channel chunk

@@ -284,6 +284,268 @@ extern "C" int rf_se3_message(const float* R0, const float* R1, const float* bas
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused radial MLP + partial-convolution message (round 4; SURVEY 7.9: "radial MLP -> (x) basis -> matvec in one kernel").
+// Reference: RadialFunc (ea/modules.py:246-284: Linear(d_edge+1 -> 32) -> LayerNorm -> ReLU -> Linear(32 -> 32) -> LayerNorm ->
+// ReLU -> Linear(32 -> mo*mi*nf)), PairwiseConv's kernel = sum_f R * basis (:287-325), GConvSE3Partial's matvec with the
+// source node's features (:612-641).  For output degree `dout` with MO channels
+//   msg[e, o, a] = sum_{di} sum_{i, f} R_di[e, (o, i, f)] * T_di[e, i, f, a],
+//   R_di[e, :] = radial MLP of net (di, dout) on feat[e, :] = [edge embedding | r],
+//   T_di[e, i, f, a] = sum_b basis_{di,dout}[e, a, b, f] h_di[src[e], i, b].
+// The round-3 form ran the MLP as ~35 small fp32 GEMM / LayerNorm launches per GSE3Res and wrote every radial output
+// R[e, (o, i, f)] (up to 512 floats per net, 15 KB per edge over the 24 nets of a structure-module call) to HBM, to be read
+// back by the message kernel: 80 % of the structure module's time (BASELINE.json configs[4]).  Here nothing between feat and
+// msg exists in memory: a thread owns TWO edges (packed as float pairs: v_pk_fma_f32, both halves share every weight), the
+// net's parameters sit in LDS and are read with wave-uniform addresses (broadcast, conflict-free), the 32-wide hidden
+// vectors and their LayerNorms live in registers, the (i, f) loop forms T on the fly from the gathered source features and
+// the edge's basis, and the MO x (2 dout + 1) outputs accumulate in registers.  fp32 FMAs throughout (se3_modules.py:164).
+// One launch per (value | key, dout).  Packed parameters of one net (host: structure.py GSE3Res._packed), fp32:
+//   [W1^T: KI x 32][b1 32][g1 32][e1 32][W2^T: 32 x 32][b2 32][g2 32][e2 32][W3: rows x 32][b3: rows],  rows = MO*mi*nf (o, i, f).
+// ------------------------------------------------------------------------------------------------
+typedef float rf_v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void radial_ln_relu(rf_v2f (&x)[32], const float* g, const float* b, float eps) {
+  rf_v2f m = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 32; ++j) m += x[j];
+  m *= (1.f / 32.f);
+  rf_v2f q = {0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    x[j] -= m;
+    q += x[j] * x[j];
+  }
+  const rf_v2f rs = {rsqrtf(q.x * (1.f / 32.f) + eps), rsqrtf(q.y * (1.f / 32.f) + eps)};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float4 gv = ((const float4*)g)[c], bv = ((const float4*)b)[c];
+    const float gg[4] = {gv.x, gv.y, gv.z, gv.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      rf_v2f y = x[4 * c + t] * rs * gg[t] + bb[t];
+      y.x = fmaxf(y.x, 0.f);
+      y.y = fmaxf(y.y, 0.f);
+      x[4 * c + t] = y;
+    }
+  }
+}
+
+template <int MO, int DOUT>
+__global__ __launch_bounds__(256) void se3_radial_message_kernel(const float* __restrict__ feat, int64_t feat_ld, int KI,
+                                                                 const float* __restrict__ net0, const float* __restrict__ net1,
+                                                                 const float* __restrict__ basis, const float* __restrict__ h0,
+                                                                 const float* __restrict__ h1, const int32_t* __restrict__ src,
+                                                                 const int32_t* __restrict__ count, float* __restrict__ msg,
+                                                                 int mi0, int mi1, float eps, int64_t capacity) {
+  constexpr int NA = 2 * DOUT + 1;
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // one net's packed parameters
+  const int tid = threadIdx.x;
+  const int64_t e0 = (int64_t)blockIdx.x * 512 + tid, e1 = e0 + 256;
+  const int64_t n = count[0] < capacity ? count[0] : capacity;
+  const bool ok0 = e0 < n, ok1 = e1 < n;
+  const int64_t ea = ok0 ? e0 : 0, eb = ok1 ? e1 : 0;  // (clamped: lanes without an edge compute on edge 0 and store nothing)
+  const int sa = src[ea], sb = src[eb];
+  rf_v2f acc[MO][NA];
+#pragma unroll
+  for (int o = 0; o < MO; ++o)
+#pragma unroll
+    for (int a = 0; a < NA; ++a) acc[o][a] = (rf_v2f){0.f, 0.f};
+  const float* bsa = basis + ea * RF_BASIS_LD;
+  const float* bsb = basis + eb * RF_BASIS_LD;
+  const float* fa = feat + ea * feat_ld;
+  const float* fb = feat + eb * feat_ld;
+  const int front = (KI + 3 + 32 + 3) * 32;  // floats before W3
+
+#pragma unroll 1
+  for (int di = 0; di < 2; ++di) {
+    const int mi = di ? mi1 : mi0;
+    if (mi <= 0) continue;  // (uniform)
+    const int nf = (di == 1 && DOUT == 1) ? 3 : 1;
+    const int rows = MO * mi * nf;
+    const float* P = di ? net1 : net0;
+    __syncthreads();  // the previous net's parameters are no longer read
+    for (int t = tid; t < (front + rows * 33) / 4; t += 256) ((float4*)sw)[t] = ((const float4*)P)[t];
+    for (int t = (front + rows * 33) / 4 * 4 + tid; t < front + rows * 33; t += 256) sw[t] = P[t];
+    __syncthreads();
+    const float* sW1 = sw;                     // [KI][32]
+    const float* sb1 = sw + KI * 32;           // b1 | g1 | e1
+    const float* sW2 = sb1 + 96;               // [32][32] (k-major)
+    const float* sb2 = sW2 + 1024;             // b2 | g2 | e2
+    const float* sW3 = sw + front;             // [rows][32]
+    const float* sb3 = sW3 + rows * 32;
+    rf_v2f hh[32];
+    {
+      // ---- layer 1: x1[j] = b1[j] + sum_k W1[j][k] feat[k]   (W1 stored k-major: one broadcast row of 32 outputs per k)
+      rf_v2f x1[32];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float4 bv = ((const float4*)sb1)[c];
+        x1[4 * c] = (rf_v2f){bv.x, bv.x}; x1[4 * c + 1] = (rf_v2f){bv.y, bv.y};
+        x1[4 * c + 2] = (rf_v2f){bv.z, bv.z}; x1[4 * c + 3] = (rf_v2f){bv.w, bv.w};
+      }
+#pragma unroll 1
+      for (int k = 0; k < KI; ++k) {
+        const rf_v2f f = {fa[k], fb[k]};
+        const float4* w = (const float4*)(sW1 + k * 32);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float4 wv = w[c];
+          x1[4 * c] += wv.x * f; x1[4 * c + 1] += wv.y * f; x1[4 * c + 2] += wv.z * f; x1[4 * c + 3] += wv.w * f;
+        }
+      }
+      radial_ln_relu(x1, sb1 + 32, sb1 + 64, eps);
+      // ---- layer 2
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const float4 bv = ((const float4*)sb2)[c];
+        hh[4 * c] = (rf_v2f){bv.x, bv.x}; hh[4 * c + 1] = (rf_v2f){bv.y, bv.y};
+        hh[4 * c + 2] = (rf_v2f){bv.z, bv.z}; hh[4 * c + 3] = (rf_v2f){bv.w, bv.w};
+      }
+#pragma unroll
+      for (int k = 0; k < 32; ++k) {
+        const float4* w = (const float4*)(sW2 + k * 32);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float4 wv = w[c];
+          hh[4 * c] += wv.x * x1[k]; hh[4 * c + 1] += wv.y * x1[k]; hh[4 * c + 2] += wv.z * x1[k]; hh[4 * c + 3] += wv.w * x1[k];
+        }
+      }
+      radial_ln_relu(hh, sb2 + 32, sb2 + 64, eps);
+    }
+    // ---- layer 3 rows (o, i, f) against T[i, f, a], accumulated over (i, f).  The weights of the NEXT row are read (8 broadcast
+    // ds_read_b128 + its bias) before the 32 dependent FMAs of the current one, across the (f, o) jobs of an input channel and
+    // across input channels: hipcc's own order read them two at a time right in front of their uses and exposed the LDS latency
+    // every four FMAs (two waves per SIMD do not hide it)
+    float4 wb[2][8];
+    float bq[2];
+    auto rd_row = [&](int row, float4 (&w)[8], float& bias) {
+      const float4* p = (const float4*)(sW3 + row * 32);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) w[c] = p[c];
+      bias = sb3[row];
+    };
+    // (measured, BASELINE configs[4]: the read-ahead pays where a channel has many rows -- MO = 32: 548 -> 491 us -- and costs
+    // registers and copies where it has four: 167 -> 206 us; those instances keep the compiler's order)
+    constexpr bool PIPE = MO >= 16;
+    if constexpr (PIPE) rd_row(0, wb[0], bq[0]);  // job (i = 0, f = 0, o = 0)
+#pragma unroll 1
+    for (int i = 0; i < mi; ++i) {
+      rf_v2f T[3][NA];
+      if (di == 0) {
+        const rf_v2f x = {h0[(int64_t)sa * mi0 + i], h0[(int64_t)sb * mi0 + i]};
+#pragma unroll
+        for (int a = 0; a < NA; ++a) T[0][a] = x * (rf_v2f){DOUT == 0 ? bsa[0] : bsa[1 + a], DOUT == 0 ? bsb[0] : bsb[1 + a]};
+      } else {
+        const float* pa = h1 + ((int64_t)sa * mi1 + i) * 3;
+        const float* pb = h1 + ((int64_t)sb * mi1 + i) * 3;
+        const rf_v2f hx = {pa[0], pb[0]}, hy = {pa[1], pb[1]}, hz = {pa[2], pb[2]};
+        if (DOUT == 0) {
+          T[0][0] = (rf_v2f){bsa[4], bsb[4]} * hx + (rf_v2f){bsa[5], bsb[5]} * hy + (rf_v2f){bsa[6], bsb[6]} * hz;
+        } else {
+#pragma unroll
+          for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+              T[f][a] = (rf_v2f){bsa[7 + (a * 3 + 0) * 3 + f], bsb[7 + (a * 3 + 0) * 3 + f]} * hx +
+                        (rf_v2f){bsa[7 + (a * 3 + 1) * 3 + f], bsb[7 + (a * 3 + 1) * 3 + f]} * hy +
+                        (rf_v2f){bsa[7 + (a * 3 + 2) * 3 + f], bsb[7 + (a * 3 + 2) * 3 + f]} * hz;
+        }
+      }
+      constexpr int NFMAX = (DOUT == 1) ? 3 : 1;   // nf of the di = 1 net (di = 0: 1); jobs j = f * MO + o, f < nf
+#pragma unroll
+      for (int j = 0; j < NFMAX * MO; ++j) {
+        const int f = j / MO, o = j % MO;
+        if (f >= nf) break;
+        // next job: (f, o + 1), (f + 1, 0) or (i + 1: f = 0, o = 0) -- one row past the net's last one at the very end: still inside
+        // this net's LDS image (its bias block follows), read and never used
+        const bool last = (j + 1 == nf * MO);
+        const int nrow = last ? (i + 1) * nf : (((j + 1) % MO) * mi + i) * nf + (j + 1) / MO;
+        if constexpr (PIPE) {
+          rd_row(nrow, wb[(j + 1) & 1], bq[(j + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          rd_row((o * mi + i) * nf + f, wb[j & 1], bq[j & 1]);
+        }
+        const float4 (&w)[8] = wb[j & 1];
+        rf_v2f r = {bq[j & 1], bq[j & 1]};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          r += w[c].x * hh[4 * c]; r += w[c].y * hh[4 * c + 1]; r += w[c].z * hh[4 * c + 2]; r += w[c].w * hh[4 * c + 3];
+        }
+#pragma unroll
+        for (int a = 0; a < NA; ++a) acc[o][a] += r * T[f][a];
+        if constexpr (PIPE) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (PIPE && ((nf * MO) & 1)) {  // odd job count: the prefetched row sits in buffer 1, the next channel starts from buffer 0
+#pragma unroll
+        for (int c = 0; c < 8; ++c) wb[0][c] = wb[1][c];
+        bq[0] = bq[1];
+      }
+    }
+  }
+  if (ok0) {
+    float* m = msg + e0 * (MO * NA);
+#pragma unroll
+    for (int o = 0; o < MO; ++o)
+#pragma unroll
+      for (int a = 0; a < NA; ++a) m[o * NA + a] = acc[o][a].x;
+  }
+  if (ok1) {
+    float* m = msg + e1 * (MO * NA);
+#pragma unroll
+    for (int o = 0; o < MO; ++o)
+#pragma unroll
+      for (int a = 0; a < NA; ++a) m[o * NA + a] = acc[o][a].y;
+  }
+}
+
+static inline int64_t radial_net_floats(int KI, int64_t rows) { return (int64_t)(KI + 3 + 32 + 3) * 32 + rows * 33; }
+
+template <int MO, int DOUT>
+static int launch_radial_message(const float* feat, int64_t feat_ld, int KI, const float* net0, const float* net1,
+                                 const float* basis, const float* h0, const float* h1, const int32_t* src, const int32_t* count,
+                                 float* msg, int mi0, int mi1, float eps, int64_t capacity, hipStream_t s) {
+  const int nf1 = DOUT == 1 ? 3 : 1;
+  const int rows = MO * (mi0 > mi1 * nf1 ? mi0 : mi1 * nf1);
+  const size_t lds = (size_t)radial_net_floats(KI, rows) * sizeof(float);
+  if (lds > 160 * 1024) return RF_EINVAL;
+  if (lds > 64 * 1024)
+    if (const int e = rf_enable_big_lds<se3_radial_message_kernel<MO, DOUT>>()) return e;
+  hipLaunchKernelGGL((se3_radial_message_kernel<MO, DOUT>), dim3(cdiv(capacity, 512)), dim3(256), lds, s, feat, feat_ld, KI, net0,
+                     net1, basis, h0, h1, src, count, msg, mi0, mi1, eps, capacity);
+  return rf_launch_status();
+}
+
+// 1 when (mo, dout, mi0, mi1, d_edge + 1) has a fused instance (rf_se3_radial_message would launch), 0 otherwise
+extern "C" int rf_se3_radial_message_supported(int mo, int dout, int mi0, int mi1, int ki) {
+  if (dout < 0 || dout > 1 || mi0 < 0 || mi1 < 0 || (mi0 == 0 && mi1 == 0) || ki < 1 || ki > 4096) return 0;
+  // instances: degree-1 outputs have 3 (layer 4: the displacement channels) or 4 (num_channels / div) channels on the forward
+  // path (rf.py:774-784); degree-0 outputs 4 or d_state
+  if (dout == 1 ? !(mo == 3 || mo == 4) : !(mo == 4 || mo == 8 || mo == 16 || mo == 32)) return 0;
+  const int nf1 = dout == 1 ? 3 : 1;
+  const int64_t rows = (int64_t)mo * (mi0 > mi1 * nf1 ? mi0 : mi1 * nf1);
+  return radial_net_floats(ki, rows) * 4 <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int rf_se3_radial_message(const float* feat, int64_t feat_ld, int ki, const float* net0, const float* net1,
+                                     const float* basis, const float* h0, const float* h1, const int32_t* src,
+                                     const int32_t* count, float* msg, int mo, int dout, int mi0, int mi1, float ln_eps,
+                                     int64_t capacity, void* stream) {
+  if (!rf_se3_radial_message_supported(mo, dout, mi0, mi1, ki)) return RF_EINVAL;
+  if (!feat || !basis || !src || !count || !msg || capacity <= 0 || feat_ld < ki || (mi0 > 0 && (!net0 || !h0)) ||
+      (mi1 > 0 && (!net1 || !h1)))
+    return RF_EINVAL;
+  if (((uintptr_t)net0 % 16) || ((uintptr_t)net1 % 16)) return RF_EALIGN;
+  hipStream_t s = (hipStream_t)stream;
+#define RF_RM(MO_, DO_)                                                                                                  \
+  if (mo == MO_ && dout == DO_)                                                                                          \
+    return launch_radial_message<MO_, DO_>(feat, feat_ld, ki, net0, net1, basis, h0, h1, src, count, msg, mi0, mi1, ln_eps, \
+                                           capacity, s);
+  RF_RM(3, 1) RF_RM(4, 1) RF_RM(4, 0) RF_RM(8, 0) RF_RM(16, 0) RF_RM(32, 0)
+#undef RF_RM
+  return RF_EINVAL;
+}
+
+// ------------------------------------------------------------------------------------------------
 // graph attention: one wave per (dst node, head); incoming edges found through the dense eid map
 // ------------------------------------------------------------------------------------------------
 #define RF_ATT_MAXPL 16  // candidates per lane: L <= 1024

@@ -38,6 +38,12 @@ class _Runtime:
     # the SE(3) stack is discontinuous (GNormBias, kNN, distance bins), so its inputs are not the place to round
     # (tools/depth_parity.py --struct-lowp measures the difference)
     struct_inputs_fp32 = True
+    # PredictionHead: remove the per-(sample, channel) mean over the picture from the projected pair tensor before it is rounded
+    # to the 16-bit operand type (PredictionHead.run; RF_HEAD_CENTER=0 restores the plain cast)
+    head_center = bool(int(__import__("os").environ.get("RF_HEAD_CENTER", "1")))
+    # SE(3) radial MLPs: last Linear inside the message kernel (csrc/se3.hip: rf_se3_radial_message); RF_SE3_UNFUSED=1 writes the
+    # radial outputs with a K = 32 GEMM and reads them back (round-3 path, kept for A/B timing and as the form for unusual shapes)
+    se3_fused_radial = not bool(int(__import__("os").environ.get("RF_SE3_UNFUSED", "0")))
     fused_favor = True  # use the fused FAVOR+ kernel when the shape allows (bf16, dim_head 64, seq 128/256)
     fused_outer_ln = not bool(int(__import__("os").environ.get("RF_NO_FUSED_OUTER_LN", "0")))  # LayerNorm(1024) in the outer-product GEMM epilogue
     fused_tied = not bool(int(__import__("os").environ.get("RF_NO_FUSED_TIED", "0")))  # tied-attention logits + softmax in one launch
@@ -1556,6 +1562,13 @@ class PredictionHead(RFModule):
         of the logit maps."""
         B, h, Lr, Cc = pair.shape
         x = ops.linear(ln(self.proj[0], pair), self.wt("p", self.proj[1]), _f(self.proj[1].bias), out_dtype=F32)
+        if RT.head_center and ops.is_h16(T()) and row_group is None:
+            # Operand conditioning for the 16-bit modes (exact in exact arithmetic): every ResNet starts conv1x1 (no bias) ->
+            # InstanceNorm (resnet.py:57-60), which is invariant to a per-channel constant of the conv's input, and the mean over
+            # the picture of 0.5 (x + x^T) is the mean of x.  At random init that constant is ~19x the part that varies over the
+            # picture (tools/precision_probe.py: the first InstanceNorm amplifies a white input error 19x), so rounding x to 16
+            # bits AFTER removing it makes the rounding relative to the information the head actually uses.
+            ops.center_channels(x)
         if row_group is None:
             xt = torch.empty_like(x)
             ops.copy4d(x, (Lr * Lr * Cc, Cc, Lr * Cc, 1), xt, (Lr * Lr * Cc, Lr * Cc, Cc, 1), (B, Lr, Lr, Cc))

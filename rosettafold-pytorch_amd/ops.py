@@ -385,6 +385,22 @@ def instnorm(x, gamma, beta, *, eps=1e-6, residual=None, act=L.ACT_NONE, out_dty
     return y, y2
 
 
+def center_channels(x, out=None):
+    """y[b, i, j, c] = x[b, i, j, c] - mean_{i,j} x[b, :, :, c]  (fp32 NHWC, in place by default): rf_instnorm_stats + the
+    centre-only form of rf_instnorm_apply (gamma = beta = NULL).  Exact in front of anything an InstanceNorm follows through
+    per-channel-linear maps (1x1 convolution -> InstanceNorm is invariant to a per-channel constant of its input)."""
+    B, H, W, Cc = x.shape
+    _need_cuda(x, out)
+    sums = torch.empty(B * Cc * 2, device=x.device, dtype=torch.float64)
+    ws_bytes = int(lib.rf_instnorm_ws_bytes(B, H * W, Cc))
+    ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+    check(lib.rf_instnorm_stats(ptr(x), dcode(x.dtype), ptr(sums), B, H * W, Cc, ptr(ws), ws_bytes, stream()), "rf_instnorm_stats")
+    y = x if out is None else out
+    check(lib.rf_instnorm_apply(ptr(x), dcode(x.dtype), ptr(sums), None, None, 0.0, None, L.ACT_NONE, ptr(y), dcode(y.dtype), None, 0,
+                                B, H * W, Cc, stream()), "rf_instnorm_apply")
+    return y
+
+
 # --------------------------------------------------------------------------------------------- misc
 def msa_embed(msa, aa_idx, emb, pe, qenc):
     B, N, L_ = msa.shape
@@ -499,6 +515,27 @@ def se3_message(R0, R1, basis, h0, h1, src, count, mo, dout, mi0, mi1, capacity)
     msg = torch.empty(capacity, mo, 2 * dout + 1, device=basis.device, dtype=F32)  # rows >= count are never read
     check(lib.rf_se3_message(ptr(R0), ptr(R1), ptr(basis), ptr(h0), ptr(h1), ptr(src), ptr(count), ptr(msg), mo, dout,
                              mi0, mi1, capacity, stream()), "rf_se3_message")
+    return msg
+
+
+def se3_radial_message_supported(mo, dout, mi0, mi1, ki):
+    return bool(lib.rf_se3_radial_message_supported(int(mo), int(dout), int(mi0), int(mi1), int(ki)))
+
+
+def se3_radial_message(feat, ki, net0, net1, basis, h0, h1, src, count, mo, dout, mi0, mi1, eps, capacity):
+    """Fused radial MLP + message (csrc/se3.hip: rf_se3_radial_message): feat fp32 [capacity, ld] = [edge embedding | r];
+    net_di = packed fp32 parameters of net (di, dout) (layout: include/rfmi.h).  Hidden vectors and radial outputs never exist."""
+    _need_cuda(feat, net0, net1, basis, h0, h1, src, count)
+    for t in (feat, net0, net1, h0, h1):
+        if t is not None and t.dtype != F32:
+            raise TypeError("se3_radial_message: fp32 operands")
+    for t in (net0, net1, h0, h1):
+        if t is not None and not t.is_contiguous():
+            raise TypeError("se3_radial_message: contiguous operands")
+    msg = torch.empty(capacity, mo, 2 * dout + 1, device=basis.device, dtype=F32)  # rows >= count are never read
+    check(lib.rf_se3_radial_message(ptr(feat), feat.stride(0), ki, ptr(net0), ptr(net1), ptr(basis), ptr(h0), ptr(h1), ptr(src),
+                                    ptr(count), ptr(msg), mo, dout, mi0, mi1, float(eps), capacity, stream()),
+          "rf_se3_radial_message")
     return msg
 
 
@@ -671,7 +708,7 @@ def ffn_fused_applies(xn, x_res, D, hidden):
     rows = x_res.numel() // D
     return (FUSE_FFN and is_h16(xn.dtype) and D in FUSE_FFN_WIDTHS and hidden % 32 == 0 and rows % 128 == 0 and rows >= 16384
             and x_res.is_contiguous() and xn.is_contiguous() and x_res.dtype == F32
-            and 288 <= hidden and hidden * 4 <= 160 * 1024 - 153 * 1024)
+            and 288 <= hidden and hidden * 4 <= 160 * 1024 - 153 * 1024 - 64)
 
 
 def ffn_fused(xn, w_packed, b1, b2, x_res, next_ln=None):

@@ -131,6 +131,14 @@ class GMABSE3(nn.Module):
         self.f_value, self.f_key, self.n_heads = dict(f_value), dict(f_key), n_heads
 
 
+def _pack_radial_net(rp):
+    """[W1^T: ki x 32][b1][ln1 gamma][ln1 beta][W2^T: 32 x 32][b2][ln2 gamma][ln2 beta][W3: rows x 32][b3: rows] fp32."""
+    n = rp.net
+    parts = [n[0].weight.t(), n[0].bias, n[1].bn.weight, n[1].bn.bias, n[3].weight.t(), n[3].bias, n[4].bn.weight, n[4].bn.bias,
+             n[6].weight, n[6].bias]
+    return torch.cat([t.detach().float().contiguous().reshape(-1) for t in parts]).contiguous()
+
+
 class GSE3Res(nn.Module):
     """ea/modules.py:777-857 with skip='cat'."""
 
@@ -170,6 +178,8 @@ class GSE3Res(nn.Module):
                     "e1": torch.cat([n[3].rp.net[1].bn.bias for n in nets], 0).float().contiguous(),
                     "g2": torch.cat([n[3].rp.net[4].bn.weight for n in nets], 0).float().contiguous(),
                     "e2": torch.cat([n[3].rp.net[4].bn.bias for n in nets], 0).float().contiguous(),
+                    # one flat fp32 buffer per net in the order the fused kernel reads it (include/rfmi.h: rf_se3_radial_message)
+                    "nets": {(which, di, do): _pack_radial_net(pc.rp) for which, di, do, pc in nets},
                 }
             object.__setattr__(self, "_rfc", pk)
         return self._rfc
@@ -191,31 +201,49 @@ class GSE3Res(nn.Module):
         pk = self._packed()
         cap, feat = g["cap"], g["feat"]
         eps = nets[0][3].rp.net[1].bn.eps
-        # radial MLPs: layer 1 for all G nets in one GEMM, grouped LayerNorm+ReLU, per-net 32x32 and output layers
-        h1 = ops.linear(feat, pk["w1"], pk["b1"], out_dtype=F32)  # [cap, G*32]
-        h1 = ops.layernorm(h1, pk["g1"], pk["e1"], eps=eps, out_dtype=F32, rows=cap * G, D=32, groups=G, act=L.ACT_RELU)
-        h2 = torch.empty_like(h1)
-        for gi, n in enumerate(nets):
-            lin = n[3].rp.net[3]
-            ops.gemm(h1, lin.weight.detach(), h2, cap, 32, 32, a_off=gi * 32, a_row=(0, 0, G * 32), c_off=gi * 32,
-                     c_row=(0, 0, G * 32), bias=_f(lin.bias))
-        h2 = ops.layernorm(h2, pk["g2"], pk["e2"], eps=eps, out_dtype=F32, rows=cap * G, D=32, groups=G, act=L.ACT_RELU)
-        R = {}
-        for gi, (which, di, do, pc) in enumerate(nets):
-            lin = pc.rp.net[6]
-            nout = lin.weight.shape[0]
-            r = torch.empty(cap, nout, device=feat.device, dtype=F32)
-            ops.gemm(h2, lin.weight.detach(), r, cap, nout, 32, a_off=gi * 32, a_row=(0, 0, G * 32), bias=_f(lin.bias))
-            R[(which, di, do)] = r
         h0 = h.get(0)
         h1f = h.get(1)
         mi0 = h0.shape[1] if h0 is not None else 0
         mi1 = h1f.shape[1] if h1f is not None else 0
+        ki = feat.shape[1]
+        slot = {(which, di, do): gi for gi, (which, di, do, _) in enumerate(nets)}
+        last = {(which, di, do): pc.rp.net[6] for which, di, do, pc in nets}
+        todo = [(which, do, mo) for which, fo in (("v", self.f_mid_out), ("k", self.f_mid_in)) for do, mo in fo.items()]
+        fused = {(which, do): RT.se3_fused_radial and ops.se3_radial_message_supported(
+            mo, do, mi0 if (which, 0, do) in last else 0, mi1 if (which, 1, do) in last else 0, ki) for which, do, mo in todo}
+        h2 = None
+        if not all(fused.values()):
+            # radial MLPs as launches (shapes without a fused instance, or RF_SE3_UNFUSED=1): layer 1 for all G nets in one GEMM,
+            # grouped LayerNorm + ReLU, per-net 32x32 layer, grouped LayerNorm + ReLU; the output layer follows per net below
+            h1 = ops.linear(feat, pk["w1"], pk["b1"], out_dtype=F32)  # [cap, G*32]
+            h1 = ops.layernorm(h1, pk["g1"], pk["e1"], eps=eps, out_dtype=F32, rows=cap * G, D=32, groups=G, act=L.ACT_RELU)
+            h2 = torch.empty_like(h1)
+            for gi, n in enumerate(nets):
+                lin = n[3].rp.net[3]
+                ops.gemm(h1, lin.weight.detach(), h2, cap, 32, 32, a_off=gi * 32, a_row=(0, 0, G * 32), c_off=gi * 32,
+                         c_row=(0, 0, G * 32), bias=_f(lin.bias))
+            h2 = ops.layernorm(h2, pk["g2"], pk["e2"], eps=eps, out_dtype=F32, rows=cap * G, D=32, groups=G, act=L.ACT_RELU)
         msg = {}
-        for which, fo in (("v", self.f_mid_out), ("k", self.f_mid_in)):
-            for do, mo in fo.items():
-                msg[(which, do)] = ops.se3_message(R.get((which, 0, do)), R.get((which, 1, do)), g["basis"], h0, h1f,
-                                                   g["src"], g["count"], mo, do, mi0, mi1, cap)
+        for which, do, mo in todo:
+            has0, has1 = (which, 0, do) in last, (which, 1, do) in last
+            if fused[(which, do)]:
+                # the whole radial MLP inside the message kernel: no hidden vectors, no [cap, mo*mi*nf] radial tensors in memory
+                msg[(which, do)] = ops.se3_radial_message(
+                    feat, ki, pk["nets"].get((which, 0, do)), pk["nets"].get((which, 1, do)), g["basis"],
+                    h0 if has0 else None, h1f if has1 else None, g["src"], g["count"], mo, do,
+                    mi0 if has0 else 0, mi1 if has1 else 0, eps, cap)
+                continue
+            R = {}
+            for di in (0, 1):
+                lin = last.get((which, di, do))
+                if lin is None:
+                    continue
+                nout = lin.weight.shape[0]
+                r = torch.empty(cap, nout, device=feat.device, dtype=F32)
+                ops.gemm(h2, lin.weight.detach(), r, cap, nout, 32, a_off=slot[(which, di, do)] * 32, a_row=(0, 0, G * 32),
+                         bias=_f(lin.bias))
+                R[di] = r
+            msg[(which, do)] = ops.se3_message(R.get(0), R.get(1), g["basis"], h0, h1f, g["src"], g["count"], mo, do, mi0, mi1, cap)
         q = self.GMAB["q"].run(h)
         fk, fv = self.f_mid_in, self.f_mid_out
         # skip connection 'cat' (GCat, ea/modules.py:903-928): the attention writes the leading channels of the

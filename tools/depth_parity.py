@@ -4,6 +4,7 @@
                                                  # exact-fp32 mode of the same library, block by block
     python tools/depth_parity.py --oracle        # 2 two-track + 2 three-track(+final) blocks, n_enc=4: every mode
                                                  # against the CPU oracle (oracle/rf_oracle.py), block by block
+    python tools/depth_parity.py --oracle --full --modes fp32,bf16,fp16   # the benchmarked 8+5 depth against the oracle
     python tools/depth_parity.py --struct-lowp   # attribution: structure-track node input in the 16-bit type (round-2 policy)
 
 Prints one JSON object (relative L2 of msa / pair / xyz after every block, logits / xyz / plddt at the end, distogram
@@ -104,7 +105,7 @@ def compare(got, ref):
 
 def run(args):
     dev = torch.device("cuda", 0)
-    n2, n3 = (2, 2) if args.oracle else (args.n_two, args.n_three)
+    n2, n3 = (2, 2) if args.oracle and not args.full else (args.n_two, args.n_three)
     cfg = dict(d_input=21, d_msa=384, d_pair=288, d_node=32, d_edge=32, d_state=32, n_two_track_blocks=n2,
                n_three_track_blocks=n3, n_encoder_layers=4, max_len=args.L + 4, n_neighbors=[128, 128, 64, 64, 64],
                p_dropout=0.0)
@@ -146,6 +147,7 @@ def run(args):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--oracle", action="store_true")
+    ap.add_argument("--full", action="store_true", help="with --oracle: the whole --n-two + --n-three depth (8+5: ~4 min of oracle on 16 cores)")
     ap.add_argument("--struct-lowp", action="store_true")
     ap.add_argument("--modes", default="bf16,fp16")
     ap.add_argument("--B", type=int, default=1)
