@@ -209,7 +209,24 @@ def parity_block(model, inputs, out_bf16, R, ms_bf16, steps=2, graph=False):
     lb, xb, pb = out_bf16
     bf = _agreement(lb, xb, pb, lg, xyz, pl)
     fp = _agreement(l16, x16, p16, lg, xyz, pl)
+    # yardstick (CPU only, tools/oracle_sensitivity.py): the ORACLE against itself at this depth with nothing changed but its weights
+    # rounded to the 16-bit type -- what no 16-bit-operand mode can beat; and the fp32 mode against the oracle at the full depth
+    yard = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_oracle_sensitivity.json")) as fh:
+            sj = json.load(fh)
+        for name in ("fp16", "bf16"):
+            r = sj[f"weights_rounded_{name}"]
+            yard[name] = {"dist_argmax_agreement": r["dist_argmax_agreement"], "rel_l2": r["rel_l2"]}
+        yard["source"] = "profiles/r04_oracle_sensitivity.json (B=1, same weights / depth; oracle vs oracle with weights rounded to the type)"
+        with open(os.path.join(ROOT, "profiles", "r04_depth_parity_oracle_full.json")) as fh:
+            dj = json.load(fh)
+        yard["fp32_mode_vs_oracle_full_depth"] = {"dist_argmax_agreement": dj["fp32"]["dist_argmax_agreement"], "rel_l2": dj["fp32"]["rel_l2"],
+                                                  "source": "profiles/r04_depth_parity_oracle_full.json (tools/depth_parity.py --oracle --full)"}
+    except (OSError, KeyError, ValueError):
+        pass
     return {"reference_mode": "exact fp32 kernels of the same library (pinned to the CPU oracle at depth: tests/test_depth_gpu.py)",
+            "oracle_weight_rounding_yardstick": yard,
             **bf, "fp32_mode_ms_per_step": ms32,
             "modes": {"bf16": {**bf, "ms_per_step": ms_bf16, "library": "librfmi.so (v_mfma_f32_16x16x32_bf16)"},
                       "fp16": {**fp, "ms_per_step": ms16, "vs_bf16_step_time": ms16 / ms_bf16,

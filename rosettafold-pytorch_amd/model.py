@@ -760,12 +760,14 @@ class PerformerSelfAttention(RFModule):
             ctx_scale = 2.0 ** -math.ceil(math.log2(max(Ls * (_shard.group_size(seq_group) if seq_group is not None else 1), 1)))
         ctx = torch.empty(S, VT_ROWS, M_PAD, device=dev, dtype=T() if seq_group is None else F32)
         ops.gemm(vt, kt, ctx, VT_ROWS, M_PAD, Ls, batch=(S, 1, 1), a_bs=(VT_ROWS * Ls, 0, 0),
-                 b_bs=(M_PAD * Ls, 0, 0), c_bs=(VT_ROWS * M_PAD, 0, 0), alpha=ctx_scale)
+                 b_bs=(M_PAD * Ls, 0, 0), c_bs=(VT_ROWS * M_PAD, 0, 0), alpha=ctx_scale if seq_group is None else 1.0)
         if seq_group is not None:
-            # the one exchange of a sequence-sharded layer: [B * Lo * H, 80, 288] fp32 partial contexts (+ k' sums in row 64)
+            # the one exchange of a sequence-sharded layer: [B * Lo * H, 80, 288] fp32 partial contexts (+ k' sums in row 64).
+            # The partial sums travel unscaled (the ranks' slices may differ in length); every rank scales its own copy of the
+            # full context when it rounds it to the 16-bit type (any power of two cancels in that rank's ratio)
             from . import shard
             shard.all_reduce_sum(ctx, seq_group)
-            ctx = ops.cast(ctx, T())
+            ctx = ops.axpby(ctx, ctx_scale, None, 0.0, torch.empty(ctx.shape, device=dev, dtype=T()))
         # numerator | denominator: num[b,p1,p2,h,0:64 | 64]
         num = torch.empty(R * H, VT_ROWS, device=dev, dtype=F32)
         ops.gemm(dq, ctx, num, Ls, VT_ROWS, M_PAD, batch=(B, Lo, H),

@@ -485,13 +485,15 @@ def knn_mask(xyz, aa_idx, k, kmin=9):
     return mask
 
 
-def edges_from_mask(mask, capacity):
-    """count = [min(edges, capacity), edges]; src/dst beyond count[0] are never read by the consumers."""
+def edges_from_mask(mask, capacity, zero_tail=False):
+    """count = [min(edges, capacity), edges]; src/dst beyond count[0] are never read by the consumers (zero_tail: zeroed
+    instead of left uninitialised -- the functional dispatcher op returns fully defined tensors)."""
     B, L_, _ = mask.shape
     dev = mask.device
     _need_cuda(mask)
-    src = torch.empty(capacity, device=dev, dtype=torch.int32)
-    dst = torch.empty(capacity, device=dev, dtype=torch.int32)
+    mk = (lambda n: zeros(n, device=dev, dtype=torch.int32)) if zero_tail else (lambda n: torch.empty(n, device=dev, dtype=torch.int32))
+    src = mk(capacity)
+    dst = mk(capacity)
     eid = torch.empty(B, L_, L_, device=dev, dtype=torch.int32)
     count = torch.empty(2, device=dev, dtype=torch.int32)
     ws = torch.empty(2 * B * L_, device=dev, dtype=torch.int32)
@@ -522,7 +524,7 @@ def se3_radial_message_supported(mo, dout, mi0, mi1, ki):
     return bool(lib.rf_se3_radial_message_supported(int(mo), int(dout), int(mi0), int(mi1), int(ki)))
 
 
-def se3_radial_message(feat, ki, net0, net1, basis, h0, h1, src, count, mo, dout, mi0, mi1, eps, capacity):
+def se3_radial_message(feat, ki, net0, net1, basis, h0, h1, src, count, mo, dout, mi0, mi1, eps, capacity, zero_tail=False):
     """Fused radial MLP + message (csrc/se3.hip: rf_se3_radial_message): feat fp32 [capacity, ld] = [edge embedding | r];
     net_di = packed fp32 parameters of net (di, dout) (layout: include/rfmi.h).  Hidden vectors and radial outputs never exist."""
     _need_cuda(feat, net0, net1, basis, h0, h1, src, count)
@@ -532,7 +534,8 @@ def se3_radial_message(feat, ki, net0, net1, basis, h0, h1, src, count, mo, dout
     for t in (net0, net1, h0, h1):
         if t is not None and not t.is_contiguous():
             raise TypeError("se3_radial_message: contiguous operands")
-    msg = torch.empty(capacity, mo, 2 * dout + 1, device=basis.device, dtype=F32)  # rows >= count are never read
+    # rows >= count are never read (zero_tail: defined anyway, for the functional dispatcher op)
+    msg = (zeros if zero_tail else torch.empty)(capacity, mo, 2 * dout + 1, device=basis.device, dtype=F32)
     check(lib.rf_se3_radial_message(ptr(feat), feat.stride(0), ki, ptr(net0), ptr(net1), ptr(basis), ptr(h0), ptr(h1), ptr(src),
                                     ptr(count), ptr(msg), mo, dout, mi0, mi1, float(eps), capacity, stream()),
           "rf_se3_radial_message")

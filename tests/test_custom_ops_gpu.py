@@ -61,6 +61,72 @@ def _cases():
     c["instance_norm_elu"] = ((xi, gi, bi, 1e-6, True), lambda: ops.instnorm(xi, gi, bi, eps=1e-6, act=L.ACT_ELU, out_dtype=F32)[0])
     xyz, aa = xyz_trace(2, 48), torch.arange(48, device=DEV).unsqueeze(0).repeat(2, 1)
     c["knn_mask"] = ((xyz, aa, 16, 9), lambda: ops.knn_mask(xyz, aa, 16, 9))
+    # ---- round 4: the remaining op groups of SURVEY 8(b)
+    Mf, Df = 16384, 288          # (the one-launch kernel takes >= 16384 rows of 288 / 384 columns)
+    xf, w1, w2 = rn(Mf, Df, seed=20, dtype=BF16), rn(4 * Df, Df, seed=21, dtype=BF16, scale=0.06), rn(Df, 4 * Df, seed=22, dtype=BF16, scale=0.03)
+    b1f, b2f, resf = 0.1 * rn(4 * Df, seed=23), 0.1 * rn(Df, seed=24), rn(Mf, Df, seed=25)
+
+    def ffn_direct():
+        out = resf.clone()
+        assert ops.ffn_fused_applies(xf, out, Df, 4 * Df)
+        ops.ffn_fused(xf, ops.ffn_pack(w1, w2, BF16), b1f, b2f, out)
+        return out
+    c["ffn"] = ((xf, w1, b1f, w2, b2f, resf), ffn_direct)
+    xp, up = rn(1, 32, 24, 96, seed=26, dtype=BF16), rn(1, 24, 4, 96, seed=27, dtype=BF16, scale=0.2)
+    c["poswise_weight"] = ((xp, up, 0.2), lambda: ops.poswise_collapsed(xp, up, 0.2))
+    Bp, Np, Lp, Dp, Hp = 1, 8, 32, 64, 4
+    lg, vp_, mp_ = rn(Bp, Lp, Lp, Hp, seed=28), rn(Bp, Np, Lp, Dp, seed=29, dtype=BF16), rn(Bp, Np, Lp, Dp, seed=30)
+
+    def pba_direct():
+        # the module's own sequence (model.py: pair_to_att + MsaUpdateWithPairLayer.run): softmax_j, v transposed, batched GEMM
+        att = torch.empty(Hp, Bp, Lp, Lp, device=DEV, dtype=BF16)
+        ops.softmax_batched(lg, 1, Lp * Hp, Hp, att, Bp * Lp * Lp, Lp, Bp * Lp, Lp, Hp)
+        v_t = vp_.permute(0, 1, 3, 2).contiguous()
+        out, dv = mp_.clone(), Dp // Hp
+        ops.gemm(att, v_t, out, Lp, Np * dv, Lp, batch=(Hp, Bp, 1), a_bs=(Bp * Lp * Lp, Lp * Lp, 0), a_row=(0, 0, Lp),
+                 b_bs=(dv * Lp, Np * Dp * Lp, 0), b_row=(dv, Dp * Lp, Lp), c_bs=(dv, Np * Lp * Dp, 0), c_row=(0, 0, Dp),
+                 c_col=(dv, Lp * Dp), residual=out)
+        return out
+    c["pair_bias_attention"] = ((lg, vp_, mp_), pba_direct)
+    qd, kd, xd, bins = rn(2, 48, 4 * 32, seed=31, scale=0.3), rn(2, 48, 4 * 32, seed=32), xyz_trace(2, 48, seed=5), torch.tensor([8., 12., 16., 20.], device=DEV)
+
+    def dist_direct():
+        att = torch.empty(2, 4, 48, 48, device=DEV, dtype=BF16)
+        ops.dist_masked_attention(qd, kd, xd, bins, att, 2, 48, 4, 32)
+        return att
+    c["masked_dist_attention"] = ((qd, kd, xd, bins), dist_direct)
+    qg, kg, vg = (rn(2, 24, 4, 8, seed=s_, dtype=BF16) for s_ in (33, 34, 35))
+    eg = rn(2, 24, 24, 32, seed=36, dtype=BF16)
+
+    def graph_direct():
+        out = torch.empty(2, 24, 32, device=DEV, dtype=F32)
+        ops.graph_attention(qg, kg, vg, eg, out, 2, 24, 4, 8, 0.35)
+        return out
+    c["graph_transformer_dense"] = ((qg, kg, vg, eg, 0.35), graph_direct)
+    mask = ops.knn_mask(xyz, aa, 16, 9)
+    cap = 2 * 48 * 32
+    c["knn_graph_csc"] = ((mask, cap), lambda: ops.edges_from_mask(mask, cap, zero_tail=True))
+    # SE(3) edge kernel + per-destination attention on that graph (layer-4 shapes of the structure module at d_state = 8)
+    from rosettafold_pytorch_amd import structure as S
+    src, dst, eid, count = ops.edges_from_mask(mask, cap, zero_tail=True)
+    edge_emb = rn(2, 48, 48, 8, seed=37)
+    basis, feat = ops.se3_edge_geometry(xyz, edge_emb, src, dst, count, cap)
+    torch.manual_seed(3)
+    pc0, pc1 = S.PairwiseConv(0, 16, 0, 8, edge_dim=8).to(DEV), S.PairwiseConv(1, 16, 0, 8, edge_dim=8).to(DEV)
+    n0, n1 = S._pack_radial_net(pc0.rp), S._pack_radial_net(pc1.rp)
+    h0, h1 = rn(96, 16, seed=38), rn(96, 16, 3, seed=39)
+    c["se3_edge_kernel"] = ((feat, n0, n1, basis, h0, h1, src, count, 8, 0, 1e-5),
+                            lambda: ops.se3_radial_message(feat, 9, n0, n1, basis, h0, h1, src, count, 8, 0, 16, 16, 1e-5, cap, zero_tail=True))
+    k0, k1, v0, v1 = rn(cap, 4, seed=40), rn(cap, 4, 3, seed=41), rn(cap, 8, seed=42), rn(cap, 4, 3, seed=43)
+    q0, q1 = rn(96, 4, 1, seed=44), rn(96, 4, 3, seed=45)
+    c["segment_softmax_sum"] = ((k0, k1, q0, q1, v0, v1, eid, 2),
+                                lambda: ops.se3_attention(k0, k1, q0, q1, v0, v1, eid, 2, 4, 4, 8, 4, 96, 48))
+    msa_tok = torch.randint(0, 21, (2, 5, 48), generator=torch.Generator().manual_seed(46)).to(DEV)
+    emb, pe, qe = rn(21, 32, seed=47), rn(64, 32, seed=48), rn(2, 32, seed=49)
+    c["embed_msa"] = ((msa_tok, aa, emb, pe, qe), lambda: ops.msa_embed(msa_tok, aa, emb, pe, qe))
+    seq_tok = msa_tok[:, 0].contiguous()
+    tl, tr, wsep, bpe, pe2 = rn(21, 32, seed=50), rn(21, 32, seed=51), rn(32, seed=52), rn(32, seed=53), rn(64, 16, seed=54)
+    c["embed_pair"] = ((seq_tok, aa, tl, tr, wsep, bpe, pe2), lambda: ops.pair_embed(seq_tok, aa, tl, tr, wsep, bpe, pe2))
     return c
 
 

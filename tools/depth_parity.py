@@ -105,7 +105,7 @@ def compare(got, ref):
 
 def run(args):
     dev = torch.device("cuda", 0)
-    n2, n3 = (2, 2) if args.oracle and not args.full else (args.n_two, args.n_three)
+    n2, n3 = (2, 2) if args.oracle and not getattr(args, 'full', False) else (args.n_two, args.n_three)
     cfg = dict(d_input=21, d_msa=384, d_pair=288, d_node=32, d_edge=32, d_state=32, n_two_track_blocks=n2,
                n_three_track_blocks=n3, n_encoder_layers=4, max_len=args.L + 4, n_neighbors=[128, 128, 64, 64, 64],
                p_dropout=0.0)
