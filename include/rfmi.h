@@ -333,6 +333,17 @@ int rf_tile_1d_feats(const float* msa1d, void* feat, int dtype, int64_t feat_ld,
 int rf_graph_attention(const void* q, const void* k, const void* v, const void* e, int dtype, float* out, int B, int L,
                        int H, int d, float scale, void* stream);
 
+/* Training-mode form of rf_graph_attention: dropout(p) on the attention probabilities (att_dropout, rf.py:628,658); mask =
+ * Philox4x32-10(seed, offset + element / 4) over the [B, H, L, L] map, like rf_dropout. */
+int rf_graph_attention_dropout(const void* q, const void* k, const void* v, const void* e, int dtype, float* out, int B, int L,
+                               int H, int d, float scale, float p, uint64_t seed, uint64_t offset, void* stream);
+
+/* nn.Dropout for the training-mode forward (rf.py:18-28, 76, 217, 265-281, 346, 455, 567, 592, 1138; resnet.py:30):
+ * y[e] = keep[e] ? x[e] / (1 - p) : 0 over n elements of dtype (fp32 or the build's 16-bit type; y may alias x), keep[e] =
+ * word (e % 4) of Philox4x32-10(key = seed, counter = offset + e / 4) >= p * 2^32.  Stateless: the caller gives every call of a
+ * forward its own offset range (ceil(n / 4) counters), so a seed reproduces the forward bit for bit.  0 <= p < 1. */
+int rf_dropout(const void* x, void* y, int dtype, float p, uint64_t seed, uint64_t offset, int64_t n, void* stream);
+
 /* MsaUpdateWithPairAndCoord attention map (rf.py:899-914): att T [B,4,L,L] = softmax_j(q.k*1 + (dist<bin ? 0 : -1e9));
  * q (pre-scaled by the caller) and k: fp32 [B,L,H*dq]; ca: fp32 xyz [B,L,3,3] (CA = atom 1). */
 int rf_dist_masked_attention(const float* q, const float* k, const float* xyz, const float* bins, void* att,

@@ -15,6 +15,7 @@ BIAS_NONE, BIAS_COL, BIAS_ROW = 0, 1, 2
 AMODE_PLAIN, AMODE_CONV3X3 = 0, 1
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+u64 = C.c_uint64
 
 
 class GemmDesc(C.Structure):
@@ -70,6 +71,8 @@ PROTOTYPES = {
     "rf_linattn_normalize": [vp, i64, vp, i32, i64, i64, i32, vp],
     "rf_tile_1d_feats": [vp, vp, i32, i64, i32, i32, i32, i32, vp],
     "rf_graph_attention": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, f32, vp],
+    "rf_graph_attention_dropout": [vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, f32, f32, u64, u64, vp],
+    "rf_dropout": [vp, vp, i32, f32, u64, u64, i64, vp],
     "rf_dist_masked_attention": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     "rf_knn_mask": [vp, vp, vp, i32, i32, i32, i32, vp],
     "rf_edges_from_mask": [vp, vp, vp, vp, vp, vp, i32, i32, i64, vp],

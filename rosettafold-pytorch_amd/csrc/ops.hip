@@ -1150,10 +1150,66 @@ extern "C" int rf_tile_1d_feats(const float* msa1d, void* feat, int dtype, int64
 }
 
 // ------------------------------------------------------------------------------------------------
-// GraphTransformer attention core: block per (b,i), thread per (h,d) channel (H*d <= 256)
+// Training-mode dropout (the reference's nn.Dropout sites, rf.py:18-28, 76, 217, 265-281, 346, 455, 567,
+// 592, 658, 1138; resnet.py:30).  Counter-based: Philox4x32-10 keyed by the caller's 64-bit seed, counter = offset + element / 4,
+// word element % 4 -- a mask depends on (seed, offset, element index) only, so a fixed seed reproduces a forward bit for bit on
+// any grid, and the host hands every dropout call of a forward its own offset range (no state on the device).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t key, unsigned (&r)[4]) {
+  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0u, c3 = 0u;
+  unsigned k0 = (unsigned)key, k1 = (unsigned)(key >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+}
+// keep[e] of the mask (seed, offset): uniform 32-bit word >= p * 2^32
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t offset, int64_t e, unsigned thresh) {
+  unsigned r[4];
+  philox4x32_10(offset + (uint64_t)(e >> 2), seed, r);
+  return r[e & 3] >= thresh;
+}
+static inline unsigned dropout_threshold(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const void* x, void* y, int dt, unsigned thresh, float inv_keep, uint64_t seed,
+                                                      uint64_t offset, int64_t n) {
+  const int64_t n4 = (n + 3) >> 2;
+  for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n4; c += (int64_t)gridDim.x * 256) {
+    unsigned r[4];
+    philox4x32_10(offset + (uint64_t)c, seed, r);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t e = 4 * c + j;
+      if (e < n) st(y, dt, e, r[j] >= thresh ? ld(x, dt, e) * inv_keep : 0.f);
+    }
+  }
+}
+
+// include/rfmi.h: rf_dropout
+extern "C" int rf_dropout(const void* x, void* y, int dtype, float p, uint64_t seed, uint64_t offset, int64_t n, void* stream) {
+  RF_CHECK_DT(dtype);
+  if (!x || !y || n < 0 || !(p >= 0.f) || !(p < 1.f)) return RF_EINVAL;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(dropout_kernel, dim3(min(cdiv((n + 3) / 4, 256), 16384u)), dim3(256), 0, (hipStream_t)stream, x, y, dtype,
+                     dropout_threshold(p), 1.f / (1.f - p), seed, offset, n);
+  return rf_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// GraphTransformer attention core: block per (b,i), thread per (h,d) channel (H*d <= 256)
+// (DROP: the reference's att_dropout on the attention probabilities, rf.py:658, for the training-mode forward)
+// ------------------------------------------------------------------------------------------------
+template <bool DROP>
 __global__ __launch_bounds__(256) void graph_attention_kernel(const void* q, const void* k, const void* v, const void* e,
-                                                              int dt, float* out, int L, int H, int d, float scale) {
+                                                              int dt, float* out, int L, int H, int d, float scale,
+                                                              unsigned thresh, float inv_keep, uint64_t seed, uint64_t offset) {
   extern __shared__ float sm[];  // logits [H][L]
   const int bi = blockIdx.x, b = bi / L;
   const int HD = H * d;
@@ -1178,7 +1234,12 @@ __global__ __launch_bounds__(256) void graph_attention_kernel(const void* q, con
     float s = 0.f;
     for (int j = lane; j < L; j += 64) s += __expf(sm[hh * L + j] - mx);
     const float inv = 1.f / wave_sum(s);
-    for (int j = lane; j < L; j += 64) sm[hh * L + j] = __expf(sm[hh * L + j] - mx) * inv;
+    for (int j = lane; j < L; j += 64) {
+      float pr = __expf(sm[hh * L + j] - mx) * inv;
+      if (DROP)  // element index of att[b, h, i, j] in the reference's [b, h, i, j] map
+        pr = dropout_keep(seed, offset, (((int64_t)b * H + hh) * L + (bi % L)) * L + j, thresh) ? pr * inv_keep : 0.f;
+      sm[hh * L + j] = pr;
+    }
   }
   __syncthreads();
   if (act) {
@@ -1195,8 +1256,21 @@ extern "C" int rf_graph_attention(const void* q, const void* k, const void* v, c
   if (H * d > 256 || d > 64 || (d & (d - 1)) != 0) return RF_EINVAL;
   const size_t lds = (size_t)H * L * sizeof(float);
   if (lds > 64 * 1024) return RF_EINVAL;
-  hipLaunchKernelGGL(graph_attention_kernel, dim3(B * L), dim3(256), lds, (hipStream_t)stream, q, k, v, e, dtype, out, L,
-                     H, d, scale);
+  hipLaunchKernelGGL(graph_attention_kernel<false>, dim3(B * L), dim3(256), lds, (hipStream_t)stream, q, k, v, e, dtype, out, L,
+                     H, d, scale, 0u, 1.f, (uint64_t)0, (uint64_t)0);
+  return rf_launch_status();
+}
+
+// training-mode form: dropout(p) on the attention probabilities (rf.py:658), mask (seed, offset) over the [B, H, L, L] map
+extern "C" int rf_graph_attention_dropout(const void* q, const void* k, const void* v, const void* e, int dtype, float* out,
+                                          int B, int L, int H, int d, float scale, float p, uint64_t seed, uint64_t offset,
+                                          void* stream) {
+  RF_CHECK_DT(dtype);
+  if (H * d > 256 || d > 64 || (d & (d - 1)) != 0 || !(p >= 0.f) || !(p < 1.f)) return RF_EINVAL;
+  const size_t lds = (size_t)H * L * sizeof(float);
+  if (lds > 64 * 1024) return RF_EINVAL;
+  hipLaunchKernelGGL(graph_attention_kernel<true>, dim3(B * L), dim3(256), lds, (hipStream_t)stream, q, k, v, e, dtype, out, L,
+                     H, d, scale, dropout_threshold(p), 1.f / (1.f - p), seed, offset);
   return rf_launch_status();
 }
 

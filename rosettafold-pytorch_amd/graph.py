@@ -41,6 +41,9 @@ class GraphedForward:
 
     def recapture(self, monotonic=None):
         """(Re)record the graph: after load_state_dict / set_compute_dtype, or for the other residue-index branch."""
+        if self.model.training:
+            raise L.RfmiError("GraphedForward records the inference forward: the dropout masks of a training-mode forward are chosen on "
+                              "the host per call (model.manual_seed / counters), a replay would repeat one set of masks; call model.eval()")
         with torch.cuda.device(self.device), torch.no_grad():
             self._dtype = M.T()   # the graph holds the kernels of the library active now
             # the recorded kernels read the prepared 16-bit weight copies by raw pointer: bring the copies in line with the live
@@ -73,6 +76,8 @@ class GraphedForward:
             if new.shape != static.shape or new.dtype != static.dtype or new.device != static.device:
                 raise ValueError(f"GraphedForward was captured for {tuple(static.shape)} {static.dtype} on {static.device}; "
                                  f"got {tuple(new.shape)} {new.dtype} on {new.device}")
+        if self.model.training:
+            raise L.RfmiError("GraphedForward replays the inference forward; the model is in training mode (model.eval() first)")
         if M.T() != self._dtype:
             raise L.RfmiError(f"GraphedForward was captured in {self._dtype} mode; set_compute_dtype changed it to {M.T()}: call recapture()")
         with torch.cuda.device(self.device):

@@ -33,6 +33,10 @@ VT_ROWS = 80   # 64 value rows + the ones row (k' sums) padded to a multiple of 
 
 class _Runtime:
     dtype = torch.bfloat16
+    # training-mode dropout: masks are Philox4x32-10(train_seed, counter); every dropout call of a forward
+    # takes the next ceil(n / 4) counters, so manual_seed(s) in front of a forward reproduces it bit for bit (csrc/ops.hip)
+    train_seed = 0
+    train_offset = 0
     cache_epoch = 0  # bumped whenever kernel-ready weight copies are dropped (graph.GraphedForward re-records on a change)
     # structure-track node input (LayerNorm(msa) -> position-weighted sum, rf.py:789-798) in fp32 also in the 16-bit modes:
     # the SE(3) stack is discontinuous (GNormBias, kNN, distance bins), so its inputs are not the place to round
@@ -95,6 +99,41 @@ def T():
     return RT.dtype
 
 
+def manual_seed(seed):
+    """Seed of the training-mode dropout masks (model.train(); the inference forward draws nothing).  Like torch.manual_seed:
+    the same seed in front of the same forward gives the same masks; consecutive forwards continue the counter stream."""
+    RT.train_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    RT.train_offset = 0
+
+
+def dropout_(t, p):
+    """In-place nn.Dropout(p) of a training-mode forward on a contiguous fp32 / 16-bit tensor (rf_dropout); identity for p <= 0."""
+    if p is None or p <= 0.0 or t.numel() == 0:
+        return t
+    if p >= 1.0:
+        return ops.fill(t, 0.0)
+    if not t.is_contiguous():
+        raise ValueError("dropout_: contiguous tensors only")
+    off = RT.train_offset
+    RT.train_offset += (t.numel() + 3) // 4
+    return ops.dropout(t, p, RT.train_seed, off)
+
+
+def _p(drop_module):
+    """p of an nn.Dropout container (0 for anything else)."""
+    return float(drop_module.p) if isinstance(drop_module, nn.Dropout) else 0.0
+
+
+def add_dropped(x_res, compute, drops):
+    """x_res += dropout_{p_k}(... dropout_{p_1}(f)) for the training-mode forward: `compute(tmp)` ADDS f to the zeroed fp32 tmp
+    (every producer of the forward path accumulates into a residual stream: handing it zeros yields f itself)."""
+    tmp = ops.zeros(*x_res.shape, device=x_res.device, dtype=F32)
+    compute(tmp)
+    for pk in drops:
+        dropout_(tmp, pk)
+    return ops.axpby(x_res, 1.0, tmp, 1.0, x_res)
+
+
 def pad8(n):
     return (n + 7) // 8 * 8
 
@@ -130,6 +169,10 @@ class RFModule(nn.Module):
 
     def __init__(self):
         super().__init__()
+        # Constructed in EVAL mode (nn.Module's default is training): this build's forward is the inference path, and the
+        # reference hard-codes non-zero dropout probabilities in places (rf.py:1015,1101; PairUpdateWithMsa's default) that a
+        # caller passing p_dropout=0 does not reach.  model.train() switches every dropout site on (Philox masks, manual_seed).
+        self.training = False
         object.__setattr__(self, "_rfc", {})
         object.__setattr__(self, "_rf_fp", None)
 
@@ -200,6 +243,16 @@ class Linear(nn.Linear):
         return ops.linear(xt, ops.cast(self.weight.detach().contiguous(), T()), _f(self.bias), out_dtype=F32)
 
 
+def project_into_residual(x, w, bias, x_res, next_ln, drops=(), xn_out=None):
+    """x_res += x @ w^T + bias, with the next LayerNorm when the fused epilogue applies (ops.linear_residual_ln); training mode:
+    `drops` = the dropouts the reference applies to the projected tensor before the residual add (then returns None)."""
+    drops = tuple(d for d in drops if d and d > 0)
+    if drops:
+        add_dropped(x_res, lambda tmp: ops.linear(x, w, bias, out=tmp, residual=tmp), drops)
+        return None
+    return ops.linear_residual_ln(x, w, bias, x_res, next_ln, xn_out)
+
+
 def ln(mod, x, out_dtype=None, **kw):
     return ops.layernorm(x, _f(mod.weight), _f(mod.bias), eps=mod.eps, out_dtype=out_dtype or T(), **kw)
 
@@ -213,12 +266,16 @@ class Residual(nn.Module):
 
     def __init__(self, fn, p_dropout=None):
         super().__init__()
+        self.training = False   # (eval by default, like every module of this build: RFModule.__init__)
         self.fn = fn
+        self.p_dropout = p_dropout
 
     def forward(self, x):
         fx = self.fn(x)
         if isinstance(fx, tuple):
             raise TypeError("Residual wraps modules that return one tensor")
+        if self.training and self.p_dropout:   # rf.py:25-26: dropout(fn(x)) + x
+            fx = dropout_(fx.float().contiguous().clone(), self.p_dropout)
         out = torch.empty(x.shape, device=x.device, dtype=F32)
         return ops.axpby(fx.contiguous(), 1.0, x.contiguous(), 1.0, out)
 
@@ -268,9 +325,18 @@ class FeedForward(RFModule):
         super().__init__()
         self.net = nn.Sequential(Linear(d_emb, d_ff), nn.ReLU(), nn.Dropout(p_dropout), Linear(d_ff, d_emb))
 
-    def apply_residual(self, xn, x_res, next_ln=None):
+    def apply_residual(self, xn, x_res, next_ln=None, drops=()):
         """x_res += W2 relu(W1 xn + b1) + b2   (x_res fp32, in place).  With `next_ln` the second GEMM's epilogue also
-        emits next_ln(x_res) (returned, or None when the fused form does not apply)."""
+        emits next_ln(x_res) (returned, or None when the fused form does not apply).
+        Training mode (self.training): dropout on the hidden activations (rf.py:276) and, from the wrapping module, `drops` on
+        the block's output before the residual add (rf.py:25-26, 330) -- two GEMMs with the hidden tensor in memory."""
+        ph = _p(self.net[2]) if self.training else 0.0
+        drops = tuple(d for d in drops if d and d > 0)
+        if ph > 0 or drops:
+            w1, b1, w2, b2 = self.wt("w1", self.net[0]), _f(self.net[0].bias), self.wt("w2", self.net[3]), _f(self.net[3].bias)
+            h = dropout_(ops.linear(xn, w1, b1, act=L.ACT_RELU), ph)
+            add_dropped(x_res, lambda tmp: ops.linear(h, w2, b2, out=tmp, residual=tmp), drops)
+            return None
         if ops.ffn_fused_applies(xn, x_res, self.net[0].in_features, self.net[0].out_features):
             # one launch, hidden activations on chip (csrc/ffn.hip); the weights are packed once per module
             wp = self.cached("ffn_packed", lambda: ops.ffn_pack(self.net[0].weight, self.net[3].weight, T()))
@@ -324,13 +390,15 @@ class SinusoidalPositionalEncoding(RFModule):
     def __init__(self, dim, max_len, p_dropout=0.1):
         super().__init__()
         self.dim, self.max_len = dim, max_len
+        self.p_dropout = p_dropout
         self.register_buffer("pos_enc", sinusoid_table(dim, max_len), persistent=False)
 
     def forward(self, x, aa_idx):
-        """x [B,N,L,dim] + pos_enc[aa_idx] broadcast over N (rf.py:72-76; dropout = identity)."""
+        """x [B,N,L,dim] + pos_enc[aa_idx] broadcast over N (rf.py:72-76; dropout: training mode only)."""
         aa_idx = aa_idx.to(x.device).contiguous()
         check_index_range(None, None, aa_idx, 1, self.max_len)
-        return ops.add_pos_enc(x.float().contiguous(), aa_idx, self.pos_enc, two_d=False)
+        y = ops.add_pos_enc(x.float().contiguous(), aa_idx, self.pos_enc, two_d=False)
+        return dropout_(y, self.p_dropout) if self.training else y
 
 
 class SinusoidalPositionalEncoding2D(RFModule):
@@ -363,8 +431,15 @@ class MsaEmbedding(RFModule):
 
     def run(self, x, aa_idx):
         """(indices already validated)"""
-        return ops.msa_embed(x.contiguous(), aa_idx.contiguous(), _f(self.to_embedding.weight), self.pos_enc.pos_enc,
-                             _f(self.query_enc.weight))
+        emb, pe, qe = _f(self.to_embedding.weight), self.pos_enc.pos_enc, _f(self.query_enc.weight)
+        pd = self.pos_enc.p_dropout if self.training else 0.0
+        if pd and pd > 0:
+            # rf.py:114-120: dropout(emb[msa] + pe[aa_idx]) + query_enc -- the dropout sits between the two additions
+            y = dropout_(ops.msa_embed(x.contiguous(), aa_idx.contiguous(), emb, pe, ops.zeros(*qe.shape, device=qe.device, dtype=F32)), pd)
+            yq = ops.msa_embed(x.contiguous(), aa_idx.contiguous(), ops.zeros(*emb.shape, device=emb.device, dtype=F32),
+                               ops.zeros(*pe.shape, device=pe.device, dtype=F32), qe)
+            return ops.axpby(y, 1.0, yq, 1.0, y)
+        return ops.msa_embed(x.contiguous(), aa_idx.contiguous(), emb, pe, qe)
 
 
 class PairEmbedding(RFModule):
@@ -429,8 +504,13 @@ class PositionWiseWeightFactor(RFModule):
         self.n_heads = n_heads
         self.d_head = d_msa // n_heads
         self.scale = self.d_head ** (-0.5)
+        self.p_dropout = p_dropout
         self.to_q = nn.Sequential(Linear(d_msa, d_msa), nn.Identity())
         self.to_k = nn.Sequential(Linear(d_msa, d_msa), nn.Identity())
+
+    def drop(self, w):
+        """rf.py:217: dropout on the softmax weights (training mode; they then no longer sum to one, as in the reference)."""
+        return dropout_(w, self.p_dropout) if self.training else w
 
     def query_proj(self, xn):
         """to_q on MSA row 0 only: [B*L, d] (T)."""
@@ -447,7 +527,7 @@ class PositionWiseWeightFactor(RFModule):
         k = ops.linear(xn, self.wt("k", self.to_k[0]), _f(self.to_k[0].bias))
         w = torch.empty(B, N, self.n_heads, Lr, device=xn.device, dtype=F32) if w_out is None else w_out
         ops.poswise(q0, D, k, D, 0, self.d_head, self.d_head, w, None, 0, 0, 0, B, N, Lr, self.n_heads, self.scale, 1.0)
-        return w
+        return self.drop(w)
 
     def weights_collapsed(self, msa, lnm, m):
         """1-head weights for the structure track, q side in fp32: w = softmax_n(scale * m[b,n,l,:] . u[b,l,:]) with
@@ -461,7 +541,7 @@ class PositionWiseWeightFactor(RFModule):
         u = ops.linear(q0, wkt, None, out_dtype=F32)
         w = torch.empty(B, N, 1, Lr, device=msa.device, dtype=F32)
         ops.poswise(u, D, m, D, 0, 0, D, w, None, 0, 0, 0, B, N, Lr, 1, self.scale, 1.0)
-        return w
+        return self.drop(w)
 
     def forward(self, msa_emb):
         w = self.weights(ops.cast(msa_emb.contiguous(), T()))
@@ -478,15 +558,18 @@ class SoftTiedAttentionOverResidues(RFModule):
         self.n_heads, self.d_head = n_heads, d_msa // n_heads
         self.scale = self.d_head ** (-0.5)
         self.return_att = return_att
+        self.p_dropout = p_dropout
         self.poswise_weight = PositionWiseWeightFactor(d_msa, n_heads, p_dropout)
         self.to_q = Linear(d_msa, d_msa)
         self.to_k = Linear(d_msa, d_msa)
         self.to_v = Linear(d_msa, d_msa)
         self.to_out = Linear(d_msa, d_msa)
 
-    def attend(self, xn, x_res, want_att, next_ln=None):
+    def attend(self, xn, x_res, want_att, next_ln=None, drops=()):
         """xn: T [B,N,L,D] (already layer-normed); x_res: fp32 [B,N,L,D] += to_out(attention).  Returns
-        (symmetrised attention map fp32 [B,L,L,H] when want_att, next_ln(x_res) when fused else None)."""
+        (symmetrised attention map fp32 [B,L,L,H] when want_att, next_ln(x_res) when fused else None).
+        Training mode: the position weights are dropped out inside (rf.py:217); `drops` = the dropouts on the projected output
+        before the residual add (this module's own, rf.py:265-267, and the wrapping EncoderLayer's, rf.py:346)."""
         B, N, Lr, D = xn.shape
         H, dh = self.n_heads, self.d_head
         dev = xn.device
@@ -494,18 +577,31 @@ class SoftTiedAttentionOverResidues(RFModule):
         if (RT.fused_tied and RT.tied_v2 and ops.is_h16(T()) and dh == 32 and Lr in (64, 128, 192, 256) and H <= 16
                 and N % 16 == 0 and N // 16 in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16) and (B * N * Lr) % 256 == 0 and B * N * Lr >= 16384
                 and (6 if Lr >= 256 else 8) * (4096 + Lr * 64) + 1024 + N * 256 <= 160 * 1024):
-            return self.attend_head_major(xn, x_res, want_att, next_ln)
+            return self.attend_head_major(xn, x_res, want_att, next_ln, drops)
         if (RT.fused_tied and RT.tied_v2 and RT.tied_fold_w and ops.is_h16(T()) and dh == 32 and Lr in (512, 768, 1024) and H <= 16
                 and ops.gemm_takes_row_scale(B * N * Lr, 2 * D, D) and N % 16 == 0 and N // 16 in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16)
                 and (B * N * Lr) % 256 == 0 and B * N * Lr >= 16384):
-            return self.attend_long_rows(xn, x_res, want_att, next_ln)
+            return self.attend_long_rows(xn, x_res, want_att, next_ln, drops)
         # one GEMM for q | k | poswise-k  (N = 3D)
         wcat = self.wcat("qkp", [self.to_q, self.to_k, pw.to_k[0]])
         bcat = self.bcat("qkp", [self.to_q, self.to_k, pw.to_k[0]])
         qkp = ops.linear(xn, wcat, bcat)  # [B,N,L,3D]
         q0 = pw.query_proj(xn)
         # w = softmax_n(q0.k_pw * scale);  q <- q * w * scale   (rf.py:252)
-        ops.poswise(q0, D, qkp, 3 * D, 2 * D, dh, dh, None, qkp, 3 * D, 0, dh, B, N, Lr, H, pw.scale, self.scale)
+        if pw.training and pw.p_dropout and pw.p_dropout > 0:
+            # training mode: the weights exist as a tensor so that the dropout can sit between the softmax and the scaling
+            w = torch.empty(B, N, H, Lr, device=dev, dtype=F32)
+            ops.poswise(q0, D, qkp, 3 * D, 2 * D, dh, dh, w, None, 0, 0, 0, B, N, Lr, H, pw.scale, 1.0)
+            pw.drop(w)
+            wl = ops.copy4d(w, (N * H * Lr, H * Lr, 1, Lr), torch.empty(B, N, Lr, H, device=dev, dtype=F32),
+                            (N * Lr * H, Lr * H, H, 1), (B, N, Lr, H))
+            ops.axpby(wl, self.scale, None, 0.0, wl)
+            qc = ops.copy4d(qkp, (N * Lr * 3 * D, Lr * 3 * D, 3 * D, 1), torch.empty(B, N, Lr, D, device=dev, dtype=T()),
+                            (N * Lr * D, Lr * D, D, 1), (B, N, Lr, D))
+            ops.scale_rows(qc, wl, B * N * Lr * H, dh, out=qc)
+            ops.copy4d(qc, (N * Lr * D, Lr * D, D, 1), qkp, (N * Lr * 3 * D, Lr * 3 * D, 3 * D, 1), (B, N, Lr, D))
+        else:
+            ops.poswise(q0, D, qkp, 3 * D, 2 * D, dh, dh, None, qkp, 3 * D, 0, dh, B, N, Lr, H, pw.scale, self.scale)
         # v transposed: v_t[b,n,(h,d),l]
         v_t = torch.empty(B, N, D, Lr, device=dev, dtype=T())
         ops.gemm(self.wt("v", self.to_v), xn, v_t, D, Lr, D, batch=(B * N, 1, 1), b_bs=(Lr * D, 0, 0),
@@ -530,10 +626,10 @@ class SoftTiedAttentionOverResidues(RFModule):
                  a_bs=(H * Lr * Lr, Lr * Lr, 0), a_row=(0, 0, Lr),
                  b_bs=(N * D * Lr, dh * Lr, 0), b_row=(dh, D * Lr, Lr),
                  c_bs=(N * Lr * D, dh, 0), c_row=(0, 0, D), c_col=(dh, Lr * D))
-        xn_next = ops.linear_residual_ln(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln)
+        xn_next = project_into_residual(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln, drops)
         return att_sym, xn_next
 
-    def attend_head_major(self, xn, x_res, want_att, next_ln=None):
+    def attend_head_major(self, xn, x_res, want_att, next_ln=None, drops=()):
         """The bench path (csrc/tied.hip): one projection GEMM writes q|k|v head-major [B,N,3H,L,32] (every contraction
         step of the attention kernels is then one contiguous tile), the position weights come from the collapsed form
         (no to_k projection over the N rows) and are applied inside the logits kernel, attention.V consumes v with
@@ -550,7 +646,7 @@ class SoftTiedAttentionOverResidues(RFModule):
         u = torch.empty(B, Lr, H, D, device=dev, dtype=T())
         ops.gemm(q0, wkt, u, B * Lr, D, dh, batch=(H, 1, 1), a_bs=(dh, 0, 0), a_row=(0, 0, D), b_bs=(dh, 0, 0),
                  b_row=(0, 0, D), c_bs=(D, 0, 0), c_row=(0, 0, H * D))
-        w = ops.poswise_collapsed(xn, u, pw.scale)  # fp32 [B,H,N,L]
+        w = pw.drop(ops.poswise_collapsed(xn, u, pw.scale))  # fp32 [B,H,N,L]
         qkv = torch.empty(B, N, G, Lr, dh, device=dev, dtype=T())
         # q * w * d_head^-0.5 (rf.py:252) in the projection's epilogue, on the fp32 accumulators: q is rounded once, after
         # the scaling, and the logits kernel neither stages the weights nor rescales its fragments (round 2: 15-20 us of VALU)
@@ -564,10 +660,10 @@ class SoftTiedAttentionOverResidues(RFModule):
         out = torch.empty(B, N, Lr, D, device=dev, dtype=T())
         ops.tied_attention(qkv[:, :, 0:H], qkv[:, :, H:2 * H], qkv[:, :, 2 * H:], out.view(B, N, Lr, H, dh).permute(0, 1, 3, 2, 4),
                            att, w=None if fold else w, qscale=1.0 if fold else self.scale, att_sym=att_sym)
-        xn_next = ops.linear_residual_ln(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln)
+        xn_next = project_into_residual(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln, drops)
         return att_sym, xn_next
 
-    def attend_long_rows(self, xn, x_res, want_att, next_ln=None):
+    def attend_long_rows(self, xn, x_res, want_att, next_ln=None, drops=()):
         """L in {512, 768, 1024} (BASELINE.json configs[3]).  Same front as attend_head_major -- collapsed position weights, one
         projection GEMM writing q|k head-major with w * d_head^-0.5 folded into q on the fp32 accumulators -- then the
         contraction-split logits kernel over 128-query x 256-key tiles (csrc/tied.hip: rf_tied_logits).  attention . V at
@@ -583,7 +679,7 @@ class SoftTiedAttentionOverResidues(RFModule):
         u = torch.empty(B, Lr, H, D, device=dev, dtype=T())
         ops.gemm(q0, wkt, u, B * Lr, D, dh, batch=(H, 1, 1), a_bs=(dh, 0, 0), a_row=(0, 0, D), b_bs=(dh, 0, 0),
                  b_row=(0, 0, D), c_bs=(D, 0, 0), c_row=(0, 0, H * D))
-        w = ops.poswise_collapsed(xn, u, pw.scale)  # fp32 [B,H,N,L]
+        w = pw.drop(ops.poswise_collapsed(xn, u, pw.scale))  # fp32 [B,H,N,L]
         G = 2 * H
         lins = [self.to_q, self.to_k]
         qk = torch.empty(B, N, G, Lr, dh, device=dev, dtype=T())
@@ -601,13 +697,13 @@ class SoftTiedAttentionOverResidues(RFModule):
                  a_bs=(H * Lr * Lr, Lr * Lr, 0), a_row=(0, 0, Lr),
                  b_bs=(N * D * Lr, dh * Lr, 0), b_row=(dh, D * Lr, Lr),
                  c_bs=(N * Lr * D, dh, 0), c_row=(0, 0, D), c_col=(dh, Lr * D))
-        xn_next = ops.linear_residual_ln(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln)
+        xn_next = project_into_residual(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln, drops)
         return att_sym, xn_next
 
     def forward(self, x):
         xn = ops.cast(x.contiguous(), T())
         out = ops.zeros(*x.shape, device=x.device, dtype=F32)
-        att, _ = self.attend(xn, out, self.return_att)
+        att, _ = self.attend(xn, out, self.return_att, drops=(self.p_dropout,) if self.training else ())
         return (out, att) if self.return_att else out
 
 
@@ -643,6 +739,7 @@ class PerformerSelfAttention(RFModule):
         super().__init__()
         inner = dim_head * heads
         self.heads, self.dim_head, self.inner = heads, dim_head, inner
+        self.p_dropout = dropout   # (performer_pytorch.SelfAttention: nn.Dropout on the projected output)
         self.generalized = generalized_attention
         self.fast_attention = _FastAttention(dim_head, int(dim_head * math.log(dim_head)))
         self.to_q = Linear(dim, inner, bias=False)
@@ -660,7 +757,7 @@ class PerformerSelfAttention(RFModule):
             return pp.to(T()).contiguous()
         return self.cached(("proj", log2e), make)
 
-    def attend(self, xn, x_res, axis, next_ln=None, seq_group=None):
+    def attend(self, xn, x_res, axis, next_ln=None, seq_group=None, drops=()):
         """xn: T [B,L1,L2,D] layer-normed input; sequences run along `axis` (1 or 2); x_res (fp32, same shape)
         += to_out(linear attention).  All intermediates are addressed by strides: no transposes.
         Returns next_ln(x_res) when the fused residual+LayerNorm epilogue applies, else None.
@@ -709,7 +806,7 @@ class PerformerSelfAttention(RFModule):
             else:
                 # whole batch elements per panel (RB rows each: any axis stays addressable inside one element)
                 pr = row_panels(R, W3 * 2, RB)
-                if pr < R:
+                if pr < R and not drops:
                     nb = pr // RB
                     qkv = torch.empty(pr, W3, device=dev, dtype=T())
                     xn2, xr2 = xn.view(R, D), x_res.view(R, -1)
@@ -725,7 +822,7 @@ class PerformerSelfAttention(RFModule):
                 qkv = ops.linear(xn, wqkv, None)
                 ops.favor_attention(qkv, pcf, o, (RB * W3, so * W3, ss * W3, dh), (RB * inner, so * inner, ss * inner),
                                     0, inner, 2 * inner, B, Lo, H, Ls, dh, m, not gen, eps)
-            return ops.linear_residual_ln(o, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln)
+            return project_into_residual(o, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln, drops)
         qk = ops.linear(xn, self.wcat("qk", [self.to_q, self.to_k]), None)  # [R, 2*inner]
         # q' [B,Lo,H,Ls,M_PAD]
         dq = torch.empty(B, Lo, H, Ls, M_PAD, device=dev, dtype=T())
@@ -776,14 +873,14 @@ class PerformerSelfAttention(RFModule):
                  c_bs=(RB * H * VT_ROWS, so * H * VT_ROWS, VT_ROWS), c_row=(0, 0, ss * H * VT_ROWS))
         o = torch.empty(R, inner, device=dev, dtype=T())
         ops.linattn_normalize(num, VT_ROWS, o, dh, R * H, dh)
-        return ops.linear_residual_ln(o, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln)
+        return project_into_residual(o, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln, drops)
 
     def forward(self, x):
         """x [S, n, dim] -> [S, n, dim] (library call surface)."""
         S_, n, D = x.shape
         xn = ops.cast(x.contiguous(), T()).view(1, S_, n, D)
         out = ops.zeros(1, S_, n, D, device=x.device, dtype=F32)
-        self.attend(xn, out, axis=2)
+        self.attend(xn, out, axis=2, drops=(self.p_dropout,) if self.training else ())
         return out.view(S_, n, D)
 
 
@@ -807,6 +904,7 @@ class EncoderLayer(RFModule):
         else:
             raise NotImplementedError
         self.ln = LayerNorm(d_msa)
+        self.p_dropout = p_dropout   # rf.py:324,346: x = orig + dropout(attn(ln(x)))
         self.ff = Residual(nn.Sequential(LayerNorm(d_msa), FeedForward(d_msa, d_ff, p_dropout=p_dropout),
                                          nn.Dropout(p_dropout)))
 
@@ -817,13 +915,17 @@ class EncoderLayer(RFModule):
         if xn is None:
             xn = ln(self.ln, x)
         att = None
+        # training mode: the attention module's own output dropout, then this layer's (rf.py:265-267 / performer, 346); the
+        # feed-forward's output dropout (rf.py:330) rides into apply_residual
+        ad = (self.attn.p_dropout, self.p_dropout) if self.training else ()
+        fd = (_p(self.ff.fn[2]),) if self.training else ()
         if self.tied:
-            att, xf = self.attn.attend(xn, x, want_att, next_ln=self.ff.fn[0])
+            att, xf = self.attn.attend(xn, x, want_att, next_ln=self.ff.fn[0], drops=ad)
         else:
-            xf = self.attn.attend(xn, x, seq_axis, next_ln=self.ff.fn[0])
+            xf = self.attn.attend(xn, x, seq_axis, next_ln=self.ff.fn[0], drops=ad)
         if xf is None:
             xf = ln(self.ff.fn[0], x)
-        return att, self.ff.fn[1].apply_residual(xf, x, next_ln)
+        return att, self.ff.fn[1].apply_residual(xf, x, next_ln, drops=fd)
 
     def forward(self, x):
         x = fresh_f32(x)
@@ -1080,6 +1182,8 @@ class PairUpdateWithMsa(RFModule):
         blk = self.resnet[1].fn
         y = conv3x3(self, "c1", blk[1], ops.cast(x, T()), 1)
         y, _ = ops.instnorm(y, _f(blk[2].weight), _f(blk[2].bias), eps=blk[2].eps, act=L.ACT_ELU, out_dtype=T())
+        if self.training:
+            dropout_(y, _p(blk[4]))   # rf.py:455
         y = conv3x3(self, "c2", blk[5], y, 1)
         out, _ = ops.instnorm(y, _f(blk[6].weight), _f(blk[6].bias), eps=blk[6].eps, residual=x, act=L.ACT_ELU,
                               out_dtype=F32)
@@ -1138,13 +1242,14 @@ class PairUpdateWithAxialAttentionLayer(RFModule):
         else:
             if xn is None:
                 xn = ln(l0, x)
-            xn = self.row_attn.attend(xn, x, axis=1, next_ln=l1, seq_group=row_group)
+            xn = self.row_attn.attend(xn, x, axis=1, next_ln=l1, seq_group=row_group,
+                                      drops=(self.row_attn.p_dropout,) if self.training else ())
         if xn is None:
             xn = ln(l1, x)
-        xn = self.col_attn.attend(xn, x, axis=2, next_ln=l2)
+        xn = self.col_attn.attend(xn, x, axis=2, next_ln=l2, drops=(self.col_attn.p_dropout,) if self.training else ())
         if xn is None:
             xn = ln(l2, x)
-        return self.ff.apply_residual(xn, x, next_ln)
+        return self.ff.apply_residual(xn, x, next_ln)   # (its hidden dropout, rf.py:519, is the FeedForward's own)
 
     def forward(self, x):
         x = fresh_f32(x)
@@ -1195,6 +1300,7 @@ class MsaUpdateWithPairLayer(RFModule):
                                       nn.Dropout(p_dropout), nn.Identity(), nn.Softmax(dim=-1))
         self.msa2value = nn.Sequential(LayerNorm(d_msa), Linear(d_msa, d_msa), nn.Identity())
         self.ff = Residual(nn.Sequential(LayerNorm(d_msa), FeedForward(d_msa, d_msa, p_dropout)), p_dropout=p_dropout)
+        self.p_dropout = p_dropout   # rf.py:586,592: dropout on the attention output before it is added to the msa
 
     def folded_att_proj(self):
         """LayerNorm affine folded into the 288->H projection: W' = W*gamma, b' = W beta + b (fp32)."""
@@ -1221,10 +1327,15 @@ class MsaUpdateWithPairLayer(RFModule):
         ops.gemm(self.wt("v", lin), xn, v_t, D, Lr, D, batch=(B * N, 1, 1), b_bs=(Lr * D, 0, 0),
                  c_bs=(D * Lr, 0, 0), c_row=(0, 0, Lr), bias=_f(lin.bias), bias_mode=L.BIAS_ROW)
         # msa += att @ v  (rf.py:592-595), scattered back to [b,n,i,(h,d)]
-        ops.gemm(att, v_t, msa, Lr, N * dv, Lr, batch=(H, B, 1),
-                 a_bs=(B * Lr * Lr, Lr * Lr, 0), a_row=(0, 0, Lr),
-                 b_bs=(dv * Lr, N * D * Lr, 0), b_row=(dv, D * Lr, Lr),
-                 c_bs=(dv, N * Lr * D, 0), c_row=(0, 0, D), c_col=(dv, Lr * D), residual=msa)
+        def attv(dst):
+            ops.gemm(att, v_t, dst, Lr, N * dv, Lr, batch=(H, B, 1),
+                     a_bs=(B * Lr * Lr, Lr * Lr, 0), a_row=(0, 0, Lr),
+                     b_bs=(dv * Lr, N * D * Lr, 0), b_row=(dv, D * Lr, Lr),
+                     c_bs=(dv, N * Lr * D, 0), c_row=(0, 0, D), c_col=(dv, Lr * D), residual=dst)
+        if self.training and self.p_dropout and self.p_dropout > 0:
+            add_dropped(msa, attv, (self.p_dropout,))
+            return self.ff.fn[1].apply_residual(ln(self.ff.fn[0], msa), msa, next_ln, drops=(self.ff.p_dropout,))
+        attv(msa)
         return self.ff.fn[1].apply_residual(ln(self.ff.fn[0], msa), msa, next_ln)
 
 
@@ -1279,6 +1390,8 @@ def pair_to_att(layers, pair, row_group=None):
     wc, bc = holder.cached(("att_fold", nl), fold)
     logits = ops.linear(xs, wc, bc, out_dtype=F32)  # [B,L,L,nl*H]
     NH = nl * H
+    if holder.training:
+        dropout_(logits, _p(holder.pair2att[3]))   # rf.py:567: Dropout sits between the projection and the softmax
     # every (layer, head) softmax in one launch: problem z = li*H + h is column z of the logits
     att_all = torch.empty(nl, H, B, Lr, Lr, device=pair.device, dtype=T())
     ops.softmax_batched(logits, 1, Lr * NH, NH, att_all, B * Lr * Lr, Lr, B * Lr, Lr, NH)
@@ -1355,6 +1468,7 @@ class GraphTransformer(RFModule):
         self.node_to_v = Linear(d_node_in, d_node_out * n_heads, bias=True)
         self.edge_emb = Linear(d_edge, d_node_out * n_heads, bias=False)
         self.n_heads, self.d_out = n_heads, d_node_out
+        self.p_dropout = p_dropout   # rf.py:628,658: att_dropout on the attention probabilities
 
     def run(self, node, edge_t):
         """node fp32 [B,L,dn]; edge_t T [B,L,L,de] -> fp32 [B,L,H*d]"""
@@ -1366,7 +1480,12 @@ class GraphTransformer(RFModule):
         v = ops.linear(nt, self.wt("v", self.node_to_v), _f(self.node_to_v.bias))
         e = ops.linear(edge_t, self.wt("e", self.edge_emb), None)
         upd = torch.empty(B, Lr, H * d, device=node.device, dtype=F32)
-        ops.graph_attention(q, k, v, e, upd, B, Lr, H, d, self.scale)
+        if self.training and self.p_dropout and self.p_dropout > 0:
+            off = RT.train_offset
+            RT.train_offset += (B * H * Lr * Lr + 3) // 4
+            ops.graph_attention(q, k, v, e, upd, B, Lr, H, d, self.scale, dropout=(self.p_dropout, RT.train_seed, off))
+        else:
+            ops.graph_attention(q, k, v, e, upd, B, Lr, H, d, self.scale)
         return ops.linear(nt, self.wt("u", self.node_update), _f(self.node_update.bias), out_dtype=F32, residual=upd)
 
     def forward(self, node_feat, edge_feat, edge_mask):
@@ -1494,6 +1613,8 @@ class ResBlock2D(RFModule):
 
         y = conv("c1", f[0], x_t)
         y, _ = ops.instnorm(y, _f(f[1].weight), _f(f[1].bias), eps=f[1].eps, act=L.ACT_ELU, out_dtype=T(), **kw)
+        if self.training:
+            dropout_(y, _p(f[3]))   # resnet.py:30
         y = conv("c2", f[4], y)
         o_f, o_t = ops.instnorm(y, _f(f[5].weight), _f(f[5].bias), eps=f[5].eps, residual=x_f, act=L.ACT_ELU,
                                 out_dtype=F32, out2_dtype=T(), **kw)
@@ -1564,6 +1685,8 @@ class PredictionHead(RFModule):
         of the logit maps."""
         B, h, Lr, Cc = pair.shape
         x = ops.linear(ln(self.proj[0], pair), self.wt("p", self.proj[1]), _f(self.proj[1].bias), out_dtype=F32)
+        if self.training:
+            dropout_(x, _p(self.proj[2]))   # rf.py:1138
         if RT.head_center and ops.is_h16(T()) and row_group is None:
             # Operand conditioning for the 16-bit modes (exact in exact arithmetic): every ResNet starts conv1x1 (no bias) ->
             # InstanceNorm (resnet.py:57-60), which is invariant to a per-channel constant of the conv's input, and the mean over

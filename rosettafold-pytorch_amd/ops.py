@@ -464,10 +464,27 @@ def tile_1d_feats(msa1d, feat, feat_ld, c0, B, L_, P2):
           "rf_tile_1d_feats")
 
 
-def graph_attention(q, k, v, e, out, B, L_, H, d, scale):
+def graph_attention(q, k, v, e, out, B, L_, H, d, scale, dropout=None):
+    """dropout = (p, seed, offset): the training-mode form (att_dropout on the probabilities, rf.py:658)."""
     _need_cuda(q, k, v, e, out)
+    if dropout is not None:
+        pd, seed, off = dropout
+        check(lib.rf_graph_attention_dropout(ptr(q), ptr(k), ptr(v), ptr(e), dcode(q.dtype), ptr(out), B, L_, H, d, scale,
+                                             float(pd), int(seed), int(off), stream()), "rf_graph_attention_dropout")
+        return
     check(lib.rf_graph_attention(ptr(q), ptr(k), ptr(v), ptr(e), dcode(q.dtype), ptr(out), B, L_, H, d, scale,
                                  stream()), "rf_graph_attention")
+
+
+def dropout(x, p, seed, offset, out=None):
+    """nn.Dropout of the training-mode forward (rf_dropout): out[e] = keep ? x[e] / (1 - p) : 0 with the Philox mask
+    (seed, offset); in place by default.  fp32 / 16-bit contiguous tensors."""
+    y = x if out is None else out
+    _need_cuda(x, y)
+    if not (x.is_contiguous() and y.is_contiguous()) or x.dtype != y.dtype:
+        raise ValueError("dropout: contiguous tensors of one dtype")
+    check(lib.rf_dropout(ptr(x), ptr(y), dcode(x.dtype), float(p), int(seed), int(offset), x.numel(), stream()), "rf_dropout")
+    return y
 
 
 def dist_masked_attention(q, k, xyz, bins, att, B, L_, H, dq):

@@ -353,6 +353,9 @@ def forward_row_sharded(model, msa, seq, aa_idx, group=None):
                                min(model.msa_emb.pos_enc.max_len, model.pair_emb.pos_enc.max_len))
     # the widest halo of the forward: dilation 8 in the prediction head's ResNets (resnet.py:47-83); decided from (L, world) alone,
     # identically on every rank, before the first exchange
+    if model.training:
+        raise NotImplementedError("the row-sharded forward is the inference path: call model.eval() (training-mode dropout is built "
+                                  "for the single-process forward only)")
     check_row_split(msa.shape[2], group_size(g), 8)
     with torch.no_grad():
         out = model.forward_validated(msa, seq, aa_idx, mono, row_group=g)

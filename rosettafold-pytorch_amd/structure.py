@@ -464,11 +464,22 @@ class TwoTrackBlock(RFModule):
         return msa, pair
 
 
+def _set_dropout(module, p):
+    """Set every dropout probability below `module` (the nn.Dropout containers and the p_dropout fields the training-mode
+    forward reads) -- the reference hard-codes 0.1 for the MsaUpdateWithPair of its three-track / final blocks."""
+    for m in module.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = p
+        if getattr(m, "p_dropout", None) is not None:
+            m.p_dropout = p
+
+
 class ThreeTrackBlock(TwoTrackBlock):
     """rf.py:971-1046."""
 
     def __init__(self, d_msa, d_pair, d_node, d_edge, d_state, n_encoder_layers, n_neighbors, p_dropout):
         super().__init__(d_msa, d_pair, n_encoder_layers, p_dropout)
+        _set_dropout(self.msa_update_with_pair, 0.1)   # rf.py:1015 (whatever the model's p_dropout)
         self.coord_update_with_msa_and_pair = CoordUpdateWithMsaAndPair(d_msa=d_msa, d_pair=d_pair, d_node=d_node,
                                                                         d_edge=d_edge, d_state=d_state,
                                                                         n_neighbors=n_neighbors, p_dropout=p_dropout)
@@ -497,6 +508,7 @@ class FinalBlock(TwoTrackBlock):
 
     def __init__(self, d_msa, d_pair, d_node, d_edge, d_state, n_encoder_layers, p_dropout, n_neighbors=32):
         super().__init__(d_msa, d_pair, n_encoder_layers, p_dropout)
+        _set_dropout(self.msa_update_with_pair, 0.1)   # rf.py:1101
         self.coord_update_with_msa_and_pair = CoordUpdateWithMsaAndPair(d_msa=d_msa, d_pair=d_pair, d_node=d_node,
                                                                         d_edge=d_edge, d_state=d_state,
                                                                         n_neighbors=n_neighbors, p_dropout=p_dropout)

@@ -1,0 +1,198 @@
+"""Training-mode forward (forward only): model.train() switches on the reference's nn.Dropout sites
+(rf.py:18-28 Residual, :76 positional encoding, :217 position weights, :265-281 attention / feed-forward, :346 EncoderLayer, :455
+ResNet, :567/:592 MSA <- pair, :658 graph attention, :1138 head; resnet.py:30) with counter-based Philox masks (rf_dropout).
+Checked: the kernel's statistics (keep rate, scaling, independence of the launch geometry), placement at the sites whose effect
+can be read off the output (zeros and 1/(1-p) multiples of the eval-mode update), fixed-seed bitwise reproducibility, eval-mode
+bitwise unchanged, p = 0 training == eval."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+if not torch.cuda.is_available():
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+import rosettafold_pytorch_amd as R  # noqa: E402
+from rosettafold_pytorch_amd import ops  # noqa: E402
+
+DEV = "cuda"
+CFG = dict(d_msa=96, d_pair=64, d_node=8, d_edge=8, d_state=8, n_two_track_blocks=1, n_three_track_blocks=2,
+           n_encoder_layers=1, max_len=80, n_neighbors=[16, 16])
+
+
+def rn(*s, seed=0):
+    return torch.randn(*s, generator=torch.Generator().manual_seed(seed + len(s) + sum(s))).to(DEV)
+
+
+def inputs(seed=0, B=2, N=8, L=32):
+    g = torch.Generator().manual_seed(seed)
+    msa = torch.randint(0, 21, (B, N, L), generator=g)
+    return msa.to(DEV), msa[:, 0].clone().to(DEV), torch.arange(L).repeat(B, 1).to(DEV)
+
+
+def flat(out):
+    return [out[0][k] for k in sorted(out[0])] + [out[1], out[2]]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("p", [0.1, 0.5])
+def test_dropout_kernel_statistics(p, dtype):
+    n = 1 << 22
+    x = torch.ones(n, device=DEV, dtype=dtype)
+    y = ops.dropout(x, p, seed=1234, offset=0, out=torch.empty_like(x))
+    keep = (y != 0)
+    rate = keep.float().mean().item()
+    assert abs(rate - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-4, rate         # binomial: 4 sigma
+    assert torch.allclose(y[keep].float(), torch.full((1,), 1 / (1 - p), device=DEV), rtol=1e-2 if dtype != torch.float32 else 1e-6)
+    # stateless: the same (seed, offset) gives the same mask, another seed / offset another one; a shifted window of the
+    # counter stream continues the first (offset counts groups of four elements)
+    assert torch.equal(y, ops.dropout(x, p, 1234, 0, out=torch.empty_like(x)))
+    assert not torch.equal(y, ops.dropout(x, p, 1235, 0, out=torch.empty_like(x)))
+    y2 = ops.dropout(x[: n - 4096], p, 1234, 1024, out=torch.empty(n - 4096, device=DEV, dtype=dtype))
+    assert torch.equal(y2, y[4096:])
+    # neighbouring elements are independent: P(keep_i and keep_{i+1}) = (1 - p)^2
+    both = (keep[:-1] & keep[1:]).float().mean().item()
+    assert abs(both - (1 - p) ** 2) < 5e-3
+
+
+def test_modules_are_built_in_eval_mode_and_train_switches_the_sites_on():
+    torch.manual_seed(3)
+    model = R.RoseTTAFold(p_dropout=0.3, **CFG).to(DEV)
+    assert not model.training and not any(m.training for m in model.modules() if isinstance(m, R.RFModule))
+    a = inputs(0)
+    R.set_compute_dtype(torch.float32)
+    try:
+        e1 = [t.clone() for t in flat(model(*a))]
+        e2 = [t.clone() for t in flat(model(*a))]
+        assert all(torch.equal(x, y) for x, y in zip(e1, e2))              # inference draws nothing
+        model.train()
+        R.manual_seed(7)
+        t1 = [t.clone() for t in flat(model(*a))]
+        R.manual_seed(7)
+        t2 = [t.clone() for t in flat(model(*a))]
+        t3 = [t.clone() for t in flat(model(*a))]                           # (the counter stream goes on: other masks)
+        assert all(torch.equal(x, y) for x, y in zip(t1, t2))              # fixed seed: bit for bit
+        assert not all(torch.equal(x, y) for x, y in zip(t1, t3))
+        assert not all(torch.equal(x, y) for x, y in zip(t1, e1))
+        assert all(torch.isfinite(x).all() for x in t1)
+        with pytest.raises(R._lib.RfmiError, match="training"):
+            R.GraphedForward(model, *a)
+        model.eval()
+        e3 = [t.clone() for t in flat(model(*a))]
+        assert all(torch.equal(x, y) for x, y in zip(e1, e3))              # back to the inference forward, bitwise
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+
+
+def test_training_with_zero_probabilities_equals_eval():
+    torch.manual_seed(4)
+    layer = R.EncoderLayer(d_msa=96, d_ff=384, n_heads=12, p_dropout=0.0, tied=True, return_att=True).to(DEV)
+    x = rn(1, 8, 32, 96)
+    R.set_compute_dtype(torch.float32)
+    try:
+        o_eval, a_eval = layer(x)
+        layer.train()
+        o_tr, a_tr = layer(x)
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    assert torch.equal(o_eval, o_tr) and torch.equal(a_eval, a_tr)
+
+
+def test_feed_forward_output_dropout_placement():
+    """Residual(Sequential(LN, FeedForward, Dropout(p))) of an EncoderLayer (rf.py:326-332) with the hidden dropout off: every
+    element of (y_train - x) is 0 or (y_eval - x) / (1 - p)."""
+    p = 0.25
+    torch.manual_seed(5)
+    ff = R.FeedForward(96, 384, 0.0).to(DEV)
+    xn, x0 = rn(64, 96, seed=1), rn(64, 96, seed=2)
+    R.set_compute_dtype(torch.float32)
+    try:
+        ye = x0.clone()
+        ff.apply_residual(xn, ye)
+        ff.train()
+        R.manual_seed(11)
+        yt = x0.clone()
+        ff.apply_residual(xn, yt, drops=(p,))
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    de, dt = (ye - x0), (yt - x0)
+    dropped = dt.abs() < 1e-12
+    assert abs(dropped.float().mean().item() - p) < 0.03
+    assert torch.allclose(dt[~dropped], de[~dropped] / (1 - p), rtol=1e-4, atol=1e-6)
+
+
+def test_hidden_dropout_changes_the_block_but_keeps_its_mean():
+    """FeedForward's own dropout on the hidden activations (rf.py:276): E[W2 dropout(h)] = W2 h -- the mean over many seeds of the
+    training-mode update approaches the eval-mode update."""
+    p = 0.2
+    torch.manual_seed(6)
+    ff = R.FeedForward(32, 128, p).to(DEV)
+    xn, x0 = rn(256, 32, seed=3), torch.zeros(256, 32, device=DEV)
+    R.set_compute_dtype(torch.float32)
+    try:
+        ye = x0.clone()
+        ff.apply_residual(xn, ye)
+        ff.train()
+        acc = torch.zeros_like(ye)
+        K = 200
+        for s_ in range(K):
+            R.manual_seed(100 + s_)
+            yt = x0.clone()
+            ff.apply_residual(xn, yt)
+            acc += yt
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    err = ((acc / K - ye).norm() / ye.norm()).item()
+    assert 0 < err < 0.08, err     # 1/sqrt(200) of the single-draw deviation
+
+
+def test_position_weights_dropout():
+    """rf.py:217: dropout AFTER the softmax over the MSA depth: the kept weights are the eval weights / (1 - p)."""
+    p = 0.3
+    torch.manual_seed(8)
+    pw = R.PositionWiseWeightFactor(96, 12, p).to(DEV)
+    x = rn(2, 8, 16, 96)
+    R.set_compute_dtype(torch.float32)
+    try:
+        we = pw(x)
+        pw.train()
+        R.manual_seed(3)
+        wt = pw(x)
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    dropped = wt == 0
+    assert abs(dropped.float().mean().item() - p) < 0.03
+    assert torch.allclose(wt[~dropped], we[~dropped] / (1 - p), rtol=1e-5)
+
+
+def test_graph_attention_dropout_rows():
+    """att_dropout on the probabilities (rf.py:658): with v = 1 and no edge term the output is the kept probability mass / (1 - p):
+    mean 1, not identically 1."""
+    B, Lr, H, d, p = 2, 48, 4, 8, 0.25
+    q, k = rn(B, Lr, H * d, seed=1), rn(B, Lr, H * d, seed=2)
+    v, e = torch.ones(B, Lr, H * d, device=DEV), torch.zeros(B, Lr, Lr, H * d, device=DEV)
+    out = torch.empty(B, Lr, H * d, device=DEV)
+    ops.graph_attention(q, k, v, e, out, B, Lr, H, d, 0.3)
+    assert torch.allclose(out, torch.ones_like(out), atol=1e-5)
+    ops.graph_attention(q, k, v, e, out, B, Lr, H, d, 0.3, dropout=(p, 5, 0))
+    assert abs(out.mean().item() - 1.0) < 0.03 and out.std().item() > 0.02
+    o2 = torch.empty_like(out)
+    ops.graph_attention(q, k, v, e, o2, B, Lr, H, d, 0.3, dropout=(p, 5, 0))
+    assert torch.equal(out, o2)
+
+
+def test_resblock_and_head_dropout_active_in_training():
+    torch.manual_seed(9)
+    head = R.PredictionHead(32, 2, 0.2).to(DEV)
+    pair = rn(1, 16, 16, 32)
+    R.set_compute_dtype(torch.float32)
+    try:
+        e = head(pair)
+        head.train()
+        R.manual_seed(1)
+        t1 = head(pair)
+        R.manual_seed(1)
+        t2 = head(pair)
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    for k in e:
+        assert torch.equal(t1[k], t2[k]) and not torch.equal(t1[k], e[k]) and torch.isfinite(t1[k]).all()
