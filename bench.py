@@ -11,7 +11,7 @@ the gather of the results to rank 0 (RCCL), inside the timed region.  Rank 0 pri
 at N=1:
   * roofline: the dominant kernel family timed live with HIP events around every rf_gemm launch of one extra profiled
     step (the library reports which kernel family each launch took: rf_gemm_last_family); achieved = algorithmic FLOPs of
-    those launches / their time.  `traffic` comes from the PMC file of THIS tree (profiles/r03_traffic_pmc.json carries a
+    those launches / their time.  `traffic` comes from the PMC file of THIS tree (profiles/r04_traffic_pmc.json carries a
     hash of csrc/); a file collected on another tree is reported as stale and `traffic` stays null.
   * parity: the SAME inputs in every compute mode of the library -- the timed bf16 path, the fp16-operand build of the
     same kernels (librfmi_f16.so) and the exact-fp32 mode (pinned to the CPU oracle at depth, tests/test_depth_gpu.py) --
@@ -21,7 +21,7 @@ at N=1:
     layer of each kind at the bench shapes (B=1), warm-up + best of 3, scaled by the layer counts.
 Other workloads: --config 4 (BASELINE.json configs[3]: B=1, N=64, L=1024) and --config 5 (configs[4]: the SE(3) structure
 module alone, B=8, L=256, k=128) print a JSON line of the same form with their own `roofline` (dominant rf_gemm family of
-that workload, PMC files profiles/r03_config{4,5}_*); no parity / cpu legs.
+that workload, PMC files profiles/r04_config{4,5}_*); no parity / cpu legs.
 """
 import argparse
 import hashlib
@@ -464,7 +464,7 @@ def main():
                        else "eager launches through the C ABI"},
         }
         full = args.config == 2 and args.dtype == "bf16"
-        pmc_tag = "r03_" if args.config == 2 else f"r03_config{args.config}_"
+        pmc_tag = "r04_" if args.config == 2 else f"r04_config{args.config}_"
         if world == 1 and args.dtype == "bf16" and args.config in (2, 4, 5) and not args.no_roofline:
             fams, shapes = profile_gemms(eager if args.config != 5 else run)
             name, (secs, flops, n, nbytes) = max(fams.items(), key=lambda kv: kv[1][0])

@@ -262,3 +262,48 @@ def test_row_panels_bitwise():
     finally:
         M.RT.mall_panel_bytes, ops.FUSE_FFN = old, old_ffn
     assert torch.equal(got, ref)
+
+
+# ---- round 4: regression tests for the round-3 advisor findings -----------------------------------------------------------------------
+@pytest.mark.parametrize("dt,tol", [(torch.bfloat16, 2e-2), (torch.float16, 4e-3)], ids=["bf16", "fp16"])
+def test_tied_row_layer_d_msa_288(dt, tol):
+    """d_msa = 288 (9 heads of 32): the q|k|v projection has N = 864, which the register-resident-weights kernel does not take, so
+    the position weights cannot ride in its epilogue (`rs`): the layer must fall back to applying them in the logits kernel
+    instead of raising RF_EINVAL (round-3 advisor finding, model.py `fold`)."""
+    from rosettafold_pytorch_amd import ops
+    assert not ops.gemm_takes_row_scale(128 * 256, 3 * 288, 288) and ops.gemm_takes_row_scale(128 * 256, 3 * 384, 384)
+    torch.manual_seed(21)
+    m = R.EncoderLayer(d_msa=288, d_ff=4 * 288, n_heads=9, p_dropout=0.0, tied=True, return_att=True).to(DEV)
+    x = rn(1, 128, 256, 288)
+    with torch.no_grad():
+        ro, ra = O.encoder_layer_tied(state(m), "m", x, 9)
+    R.set_compute_dtype(dt)
+    try:
+        out, att = m(x.to(DEV))
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    assert rel(out, ro) < tol and rel(att, ra) < 2 * tol, (rel(out, ro), rel(att, ra))
+
+
+def test_performer_gemm_chain_fp16_range_L1024():
+    """fp16 operands (range 65504): the UNFUSED Performer chain (non-fused shapes, the sequence-sharded 'contexts' mode) stores the
+    contexts k'^T v and the k' sums over the whole sequence in the 16-bit type; with large-magnitude keys / values at L = 1024 they
+    leave fp16's range unless they are scaled by 2^-ceil(log2 L) as the fused kernel does (round-3 advisor finding)."""
+    torch.manual_seed(22)
+    m = R.PerformerSelfAttention(dim=288, heads=8, generalized_attention=True).to(DEV)
+    with torch.no_grad():
+        m.to_k.weight.mul_(6.0)
+        m.to_v.weight.mul_(24.0)
+    x = 3.0 * rn(2, 1024, 288)
+    with torch.no_grad():
+        ref = O.performer_self_attention(state(m), "m", x, 8, True)
+    R.set_compute_dtype(torch.float16)
+    old = R.RT.fused_favor
+    try:
+        R.RT.fused_favor = False      # the GEMM chain
+        got = m(x.to(DEV))
+    finally:
+        R.RT.fused_favor = old
+        R.set_compute_dtype(torch.bfloat16)
+    assert torch.isfinite(got).all()
+    assert rel(got, ref) < 1e-2, rel(got, ref)

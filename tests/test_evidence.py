@@ -11,8 +11,8 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
-@pytest.mark.parametrize("name", ["r03_traffic_pmc.json", "r03_mfma_pmc.json", "r03_config4_traffic_pmc.json",
-                                  "r03_config4_mfma_pmc.json", "r03_config5_traffic_pmc.json", "r03_config5_mfma_pmc.json"])
+@pytest.mark.parametrize("name", ["r04_traffic_pmc.json", "r04_mfma_pmc.json", "r04_config4_traffic_pmc.json",
+                                  "r04_config4_mfma_pmc.json", "r04_config5_traffic_pmc.json", "r04_config5_mfma_pmc.json"])
 def test_pmc_files_belong_to_this_tree(name):
     with open(os.path.join(ROOT, "profiles", name)) as fh:
         pm = json.load(fh)
@@ -24,8 +24,8 @@ BASE_KEYS = {"metric": str, "value": float, "unit": str, "n_gpus": int, "steps":
              "higher_is_better": bool, "scaling": str, "dtype": str, "data": str, "config": dict}
 
 
-@pytest.mark.parametrize("name,full", [("r03_bench_default.json", True), ("r03_bench_config4.json", False),
-                                       ("r03_bench_config5.json", False)])
+@pytest.mark.parametrize("name,full", [("r04_bench_default.json", True), ("r04_bench_config4.json", False),
+                                       ("r04_bench_config5.json", False)])
 def test_committed_bench_lines_keep_the_contract(name, full):
     with open(os.path.join(ROOT, "profiles", name)) as fh:
         d = json.loads(fh.read().strip().splitlines()[-1])
