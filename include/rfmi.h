@@ -185,7 +185,10 @@ int rf_tied_attention(const void* q, const void* k, const void* v, const int64_t
  * for chunk c of 32 hidden units, first D/32 * 2 pieces of W1, then D/16 pieces of W2, a piece = 64 lanes x 8 elements,
  * lane = 16 fq + fr:
  *   W1 piece (ks, ht):  element j of the lane = W1[32 c + 16 ht + fr][32 ks + 8 fq + j]          (W1: [hidden, D])
- *   W2 piece (nt):      element j of the lane = W2[16 nt + fr][32 c + 16 (j >> 2) + 4 fq + (j & 3)]  (W2: [D, hidden])
+ *   W2 piece (nt):      element j of the lane = W2[row(nt, fr)][32 c + 16 (j >> 2) + 4 fq + (j & 3)]  (W2: [D, hidden]) with
+ *                       row(nt, fr) = 16 nt + fr for D = 288 and, for D = 384 (an even number of column tiles per wave: the lane's
+ *                       values of two tiles are 8 consecutive columns, 16-byte pieces of the LayerNorm copy),
+ *                       row = 192 (nt / 12) + 32 (i >> 1) + 8 (fr >> 2) + 4 (i & 1) + (fr & 3), i = nt % 12  (ops.ffn_pack)
  * (ops.ffn_pack builds it once per module).  b1 [hidden], b2 [D], gamma / beta [D]: fp32. */
 int rf_ffn_fused(const void* x, int64_t ldx, const void* w_packed, const float* b1, const float* b2, const float* residual,
                  int64_t ldr, float* out, int64_t ldo, void* ln_out, int64_t ldn, const float* ln_gamma,

@@ -32,7 +32,7 @@
 // compile-time ablation (tuning only, results WRONG when non-zero; tools/ffn_ablation.sh builds one library per value):
 // 1 no MFMA, 2 fragment reads only for the first pieces, 4 DMAs into the dump area, 8 no epilogue, 16 no DMA at all, 32 no exchange,
 // 64 residual not added, 128 no output stores, 256 no residual slots, 512 residual slots filled from the (L2-resident) weights,
-// 1024 every workgroup walks the chunks in the same order
+// 1024 every workgroup walks the chunks in the same order, 2048 no LayerNorm-copy stores, 4096 no pair exchange of the row statistics
 #ifndef FFN_ABL
 #define FFN_ABL 0
 #endif
@@ -232,7 +232,8 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
   constexpr int WAIT0 = PD * (DIST - 1);
   constexpr int WAITF = WAIT0 + S1;                                 // first tile: + the residual loads
   constexpr int WAIT1 = WAIT0 + 2 * S1 < 63 ? WAIT0 + 2 * S1 : 63;  // + stores (fp32 rows) + residual loads (as many)
-  constexpr int WAIT2 = WAIT0 + 3 * S1 < 63 ? WAIT0 + 3 * S1 : 63;  // + the LayerNorm copy's stores
+  constexpr int LNST = (NTH % 2 == 0) ? S1 / 2 : S1;                // stores of the LayerNorm copy (16-byte pieces when the column tiles pair up)
+  constexpr int WAIT2 = WAIT0 + 2 * S1 + LNST < 63 ? WAIT0 + 2 * S1 + LNST : 63;  // + the LayerNorm copy's stores
   int c_slot = late ? NSTG - 1 : 0;  // (a late wave's dummy first step moves it to slot 0)
   int post = DIST;  // steps left whose DMAs were issued before this tile's residual loads (and the last epilogue's stores)
   bool first = true;
@@ -274,7 +275,14 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
     } while ((unsigned)__builtin_amdgcn_readfirstlane((int)v) < fl_seq);  // (the partner may already have published its next one)
   };
   const unsigned b1_rd = (unsigned)(B1_OFF + fq * 16);  // + 128 c: b1[32 c + 4 fq ..], + 64: the second hidden tile
-  const int col0 = ch * (NTH * 16) + 4 * fq;
+  // Output-column order of a wave's NTH column tiles.  Plain: tile i, MFMA row r -> column 16 i + r, a lane (rows 4 fq .. 4 fq + 3)
+  // holds 4 consecutive columns per tile.  PAIRED (even NTH; the packed W2 carries the same row permutation, ops.ffn_pack): tile i,
+  // row r -> column 32 (i >> 1) + 8 (r >> 2) + 4 (i & 1) + (r & 3): the lane's values of tiles 2 q and 2 q + 1 are EIGHT consecutive
+  // columns, so the LayerNorm copy leaves as 16-byte pieces (8-byte pieces cost ~2x per byte: FFN_ABL 2048: 462 -> 423 us) and the
+  // fp32 rows as 32 contiguous bytes per lane.
+  constexpr bool PAIRED = NTH % 2 == 0;
+  auto ctile = [](int i) constexpr { return PAIRED ? 32 * (i >> 1) + 4 * (i & 1) : 16 * i; };  // column offset of tile i from col0
+  const int col0 = ch * (NTH * 16) + (PAIRED ? 8 : 4) * fq;
 
 #pragma unroll 1
   for (int s = 0; s < DIST; ++s) {
@@ -291,6 +299,11 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
     if (++c_slot == NSTG) c_slot = 0;
     dma_all();
   };
+  // (measured: priority 1 for the late half: pair shape 574-580 -> 560 us, MSA shape unchanged: profiles/r04_ffn_bench_prio.log)
+#ifndef FFN_LATE_PRIO
+#define FFN_LATE_PRIO 1
+#endif
+  if (late && FFN_LATE_PRIO) __builtin_amdgcn_s_setprio(FFN_LATE_PRIO);
   if (late) idle_step();
 
   for (int it = 0;; ++it) {
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
         if (FFN_ABL & (8 | 64))
           y[i][tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         else
-          asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(y[i][tt]) : "v"(rrow), "i"(i * 64));
+          asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(y[i][tt]) : "v"(rrow), "i"(ctile(i) * 4));
       }
     }
     // ---- input rows of this wave: token tile ch of its group, KS fragments, resident for the tile ----------------------------
@@ -407,7 +420,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
     {
       f32x4 b2[NTH];
 #pragma unroll
-      for (int i = 0; i < NTH; ++i) FFN_RD(b2[i], cst, i * 64);
+      for (int i = 0; i < NTH; ++i) FFN_RD(b2[i], cst, ctile(i) * 4);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int i = 0; i < NTH; ++i) asm volatile("" : "+v"(b2[i]));
@@ -418,7 +431,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
 #pragma unroll
         for (int i = 0; i < NTH; ++i) {
           y[i][tt] += b2[i];
-          if (!(FFN_ABL & 128)) *(f32x4*)(orow + i * 16) = y[i][tt];
+          if (!(FFN_ABL & 128)) *(f32x4*)(orow + ctile(i)) = y[i][tt];
           s += (y[i][tt][0] + y[i][tt][1]) + (y[i][tt][2] + y[i][tt][3]);
         }
         s += __shfl_xor(s, 16, 64);
@@ -430,7 +443,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
       ffn_lds_write8(xb_own, sm[0], sm[1]);
       if constexpr (STG) {
         pair_publish();
-        pair_acquire();
+        if (!(FFN_ABL & 4096)) pair_acquire();
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -452,7 +465,7 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
       ffn_lds_write8(xb_own + 8, sq[0], sq[1]);   // (the other 8 bytes of the lane's 16-byte cell: the partner may still be reading the first)
       if constexpr (STG) {
         pair_publish();
-        pair_acquire();
+        if (!(FFN_ABL & 4096)) pair_acquire();
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -462,15 +475,15 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) rstd[tt] = rsqrtf((sq[tt] + __uint_as_float(tt ? o2.y : o2.x)) * (1.f / D) + p.eps);
       h16_t* lrow = p.ln + ((int64_t)tile * 128 + g * 32 + fr) * p.ldn + col0;
-      constexpr int GB = 3;  // column tiles per batch of gamma / beta reads
+      constexpr int GB = PAIRED ? 4 : 3;  // column tiles per batch of gamma / beta reads
       static_assert(NTH % GB == 0, "gamma / beta read batches");
 #pragma unroll
       for (int b = 0; b < NTH / GB; ++b) {
         f32x4 gm[GB], be[GB];
 #pragma unroll
         for (int k = 0; k < GB; ++k) {
-          FFN_RD(gm[k], cst, (b * GB + k) * 64 + D * 4);
-          FFN_RD(be[k], cst, (b * GB + k) * 64 + D * 8);
+          FFN_RD(gm[k], cst, ctile(b * GB + k) * 4 + D * 4);
+          FFN_RD(be[k], cst, ctile(b * GB + k) * 4 + D * 8);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -478,12 +491,27 @@ __global__ __launch_bounds__(512) void ffn_fused_kernel(const FfnP p) {
           asm volatile("" : "+v"(gm[k]));
           asm volatile("" : "+v"(be[k]));
           const int i = b * GB + k;
+          if constexpr (PAIRED) {
+            if (k & 1) continue;   // tiles i, i + 1 together: eight consecutive columns of the lane, one 16-byte store
+            asm volatile("" : "+v"(gm[k + 1]));
+            asm volatile("" : "+v"(be[k + 1]));
 #pragma unroll
-          for (int tt = 0; tt < 2; ++tt) {
-            ffn_u32x2 o;
-            o.x = rf_pack2_h16(y[i][tt][0] * rstd[tt] * gm[k][0] + be[k][0], y[i][tt][1] * rstd[tt] * gm[k][1] + be[k][1]);
-            o.y = rf_pack2_h16(y[i][tt][2] * rstd[tt] * gm[k][2] + be[k][2], y[i][tt][3] * rstd[tt] * gm[k][3] + be[k][3]);
-            *(ffn_u32x2*)(lrow + (int64_t)(tt * 16) * p.ldn + i * 16) = o;
+            for (int tt = 0; tt < 2; ++tt) {
+              ffn_u32x4 o;
+              o.x = rf_pack2_h16(y[i][tt][0] * rstd[tt] * gm[k][0] + be[k][0], y[i][tt][1] * rstd[tt] * gm[k][1] + be[k][1]);
+              o.y = rf_pack2_h16(y[i][tt][2] * rstd[tt] * gm[k][2] + be[k][2], y[i][tt][3] * rstd[tt] * gm[k][3] + be[k][3]);
+              o.z = rf_pack2_h16(y[i + 1][tt][0] * rstd[tt] * gm[k + 1][0] + be[k + 1][0], y[i + 1][tt][1] * rstd[tt] * gm[k + 1][1] + be[k + 1][1]);
+              o.w = rf_pack2_h16(y[i + 1][tt][2] * rstd[tt] * gm[k + 1][2] + be[k + 1][2], y[i + 1][tt][3] * rstd[tt] * gm[k + 1][3] + be[k + 1][3]);
+              if (!(FFN_ABL & 2048)) *(ffn_u32x4*)(lrow + (int64_t)(tt * 16) * p.ldn + ctile(i)) = o;
+            }
+          } else {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+              ffn_u32x2 o;
+              o.x = rf_pack2_h16(y[i][tt][0] * rstd[tt] * gm[k][0] + be[k][0], y[i][tt][1] * rstd[tt] * gm[k][1] + be[k][1]);
+              o.y = rf_pack2_h16(y[i][tt][2] * rstd[tt] * gm[k][2] + be[k][2], y[i][tt][3] * rstd[tt] * gm[k][3] + be[k][3]);
+              if (!(FFN_ABL & 2048)) *(ffn_u32x2*)(lrow + (int64_t)(tt * 16) * p.ldn + i * 16) = o;
+            }
           }
         }
       }

@@ -708,7 +708,17 @@ def ffn_pack(w1, w2, dtype=None):
         raise ValueError(f"ffn_pack: w1 {tuple(w1.shape)} / w2 {tuple(w2.shape)}")
     NC, KS, NT = hid // 32, D // 32, D // 16
     w1 = w1.detach().float().view(NC, 2, 16, KS, 4, 8).permute(0, 3, 1, 4, 2, 5)      # (c, ks, ht, fq, fr, j)
-    w2 = w2.detach().float().view(NT, 16, NC, 2, 4, 4).permute(2, 0, 4, 1, 3, 5)      # (c, nt, fq, fr, j >> 2, j & 3)
+    w2 = w2.detach().float()
+    NTH = NT // 2
+    if NTH % 2 == 0:
+        # paired column order of the kernel (csrc/ffn.hip: PAIRED): within a wave's half of the columns, MFMA tile i, row r holds
+        # output column 32 (i >> 1) + 8 (r >> 2) + 4 (i & 1) + (r & 3) -- a lane's values of tiles 2 q, 2 q + 1 are 8 consecutive columns
+        i = torch.arange(NTH).view(NTH, 1)
+        r = torch.arange(16).view(1, 16)
+        col = 32 * (i // 2) + 8 * (r // 4) + 4 * (i % 2) + (r % 4)                    # [NTH, 16]
+        rows = torch.cat([half * NTH * 16 + col.reshape(-1) for half in range(2)]).to(w2.device)
+        w2 = w2[rows]
+    w2 = w2.view(NT, 16, NC, 2, 4, 4).permute(2, 0, 4, 1, 3, 5)      # (c, nt, fq, fr, j >> 2, j & 3)
     packed = torch.cat([w1.reshape(NC, -1), w2.reshape(NC, -1)], 1)
     return packed.to(dtype if dtype is not None else h16()).contiguous()
 
