@@ -151,6 +151,32 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(const WregP p) {
   for (int k = 0; k < 4; ++k) s_rd[k] = S % 16 == 0 ? (((4 * k + fq) ^ fr) << 4) : ((4 * k + (fq ^ swz(fr))) << 4);
   char* const strip = smem + STRIP0 + wave * STRIP;
 
+  // Row-group scale (rf_gemm_desc.rs: the tied attention's position weights folded into q): a per-lane gather of RS fp32 values
+  // per row tile.  As plain loads hipcc waited for them with s_waitcnt vmcnt(0) -- five times per tile -- which drained the DMA
+  // ring and every posted store (the q|k|v projection of the tied attention ran at 2.4 TB/s against 3.2-3.8 for its siblings).
+  // They are issued from inline asm ONE TILE AHEAD, between the MFMAs and the stores of the previous tile: at their use only that
+  // tile's stores and this tile's DMAs are younger, so the counted wait below releases them without touching either.
+  constexpr int RS = WRT * WCT;
+  const bool has_rs = p.rs != nullptr && n0 < p.rs_ncols && cols_live;  // (wave-uniform)
+  float rsv[WRT][WCT];
+  auto rs_issue = [&](int it_) {
+    const int mt_ = slot + it_ * p.per;
+    const int mtc = mt_ < p.ntm ? mt_ : p.ntm - 1;   // (past the end: a valid address, the values are never used)
+#pragma unroll
+    for (int i = 0; i < WRT; ++i) {
+      const int m = mtc * TMR + wr * (16 * WRT) + i * 16 + fr;
+      const int qb = m / p.rs_rpb;
+      const float* rsm = p.rs + (int64_t)qb * p.rs_bstride + (m - qb * p.rs_rpb);
+#pragma unroll
+      for (int j = 0; j < WCT; ++j) {
+        const int n = n0 + j * 16;
+        const float* src = rsm + (int64_t)((n < p.rs_ncols ? n : 0) / p.rs_cg) * p.rs_rpb;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(rsv[i][j]) : "v"(src) : "memory");
+      }
+    }
+  };
+
+  if (has_rs) rs_issue(0);  // (the oldest operations of the wave: in front of the prologue's DMAs)
 #pragma unroll
   for (int s = 0; s < NSTG - 1; ++s) stage(s);
   for (int it = 0;; ++it) {
@@ -161,7 +187,16 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(const WregP p) {
     // (a wave whose columns lie beyond N issues no stores at all: its count holds DMAs only)
     if (!cols_live)
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * (NSTG - 2)) : "memory");
-    else if (it >= NSTG - 1)
+    else if (has_rs) {
+      // + the scale loads: the set of tile it + 1 is issued in iteration it, in front of that tile's stores
+      static_assert(PD * (NSTG - 2) + (PS + RS) * (NSTG - 1) <= 63, "vmcnt range");
+      if (it >= NSTG - 1)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * (NSTG - 2) + (PS + RS) * (NSTG - 1)) : "memory");
+      else if (it == 0)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * (NSTG - 2)) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * (NSTG - 2) + PS + RS) : "memory");
+    } else if (it >= NSTG - 1)
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * (NSTG - 2) + PS * (NSTG - 1)) : "memory");
     else if (it == 0)
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * (NSTG - 2)) : "memory");
@@ -191,21 +226,18 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(const WregP p) {
             acc[i][j] = rf_mfma16(wf[j][s], af[i], acc[i][j], 0, 0, 0);
       }
     }
-    if (p.rs && n0 < p.rs_ncols) {  // (wave-uniform; rs_cg % 16 == 0: a 16-column tile lies inside one column group)
+    if (has_rs) {  // (wave-uniform; rs_cg % 16 == 0: a 16-column tile lies inside one column group)
+      // this tile's scales (issued one tile ago): younger are the previous tile's stores and this iteration's DMAs (the first
+      // tile's set is older than the whole prologue: the same count holds)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD + PS) : "memory");
 #pragma unroll
-      for (int i = 0; i < WRT; ++i) {
-        const int m = mt * TMR + wr * (16 * WRT) + i * 16 + fr;
-        const int qb = m / p.rs_rpb;
-        const float* rsm = p.rs + (int64_t)qb * p.rs_bstride + (m - qb * p.rs_rpb);
+      for (int i = 0; i < WRT; ++i)
 #pragma unroll
         for (int j = 0; j < WCT; ++j) {
-          const int n = n0 + j * 16;
-          if (n < p.rs_ncols) {
-            const float sc = rsm[(int64_t)(n / p.rs_cg) * p.rs_rpb] * p.rs_alpha;
-            acc[i][j] *= sc;
-          }
+          asm volatile("" : "+v"(rsv[i][j]));
+          if (n0 + j * 16 < p.rs_ncols) acc[i][j] *= rsv[i][j] * p.rs_alpha;
         }
-      }
+      rs_issue(it + 1);  // (behind the MFMAs, in front of this tile's stores)
     }
     // ---- epilogue: wave-private strip (in-order LDS per wave: no barrier), 16-byte row-contiguous stores -----------
     const float lo = p.relu ? 0.f : -INFINITY;
