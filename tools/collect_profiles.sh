@@ -3,8 +3,8 @@
 # summaries copied next to the other gpurun_out files (copy the ones to keep into profiles/ afterwards).
 #   bash tools/collect_profiles.sh <tag> [config]
 set -u
-TAG=${1:-r03}
-CFG=${2:-2}     # bench.py --config (2 = the headline workload; 4 / 5: tag the files r03_config4 / r03_config5)
+TAG=${1:-r04}
+CFG=${2:-2}     # bench.py --config (2 = the headline workload; 4 / 5: tag the files r04_config4 / r04_config5)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
