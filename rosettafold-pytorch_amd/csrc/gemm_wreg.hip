@@ -154,12 +154,16 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(const WregP p) {
   // Row-group scale (rf_gemm_desc.rs: the tied attention's position weights folded into q): a per-lane gather of RS fp32 values
   // per row tile.  As plain loads hipcc waited for them with s_waitcnt vmcnt(0) -- five times per tile -- which drained the DMA
   // ring and every posted store (the q|k|v projection of the tied attention ran at 2.4 TB/s against 3.2-3.8 for its siblings).
-  // They are issued from inline asm ONE TILE AHEAD, between the MFMAs and the stores of the previous tile: at their use only that
-  // tile's stores and this tile's DMAs are younger, so the counted wait below releases them without touching either.
+  // They are issued from inline asm ONE TILE AHEAD, at the top of the previous iteration IN FRONT of its DMAs: vmcnt retires in
+  // order, so a wait for a load also waits for every older operation -- with the loads issued behind an iteration's DMAs (first
+  // form) the wait for them forced the DMAs of the ring's newest slot to land one iteration after their issue (162 us per launch);
+  // in front of them, the two newest DMA sets and the previous tile's stores stay in flight (counted wait below).
   constexpr int RS = WRT * WCT;
-  const bool has_rs = p.rs != nullptr && n0 < p.rs_ncols && cols_live;  // (wave-uniform)
-  float rsv[WRT][WCT];
-  auto rs_issue = [&](int it_) {
+  // (wave-uniform; instances without the split-C epilogue never see a scale: rf_gemm_wreg_try declines rs there, so the two
+  // register sets cost them nothing)
+  const bool has_rs = CS && p.rs != nullptr && n0 < p.rs_ncols && cols_live;
+  float rs_a[WRT][WCT], rs_b[WRT][WCT];  // two register sets: tile it's scales are used while tile it + 1's are in flight
+  auto rs_issue = [&](int it_, float (&rsv)[WRT][WCT]) {
     const int mt_ = slot + it_ * p.per;
     const int mtc = mt_ < p.ntm ? mt_ : p.ntm - 1;   // (past the end: a valid address, the values are never used)
 #pragma unroll
@@ -176,26 +180,29 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(const WregP p) {
     }
   };
 
-  if (has_rs) rs_issue(0);  // (the oldest operations of the wave: in front of the prologue's DMAs)
+  if (has_rs) rs_issue(0, rs_a);  // (the oldest operations of the wave: in front of the prologue's DMAs)
 #pragma unroll
   for (int s = 0; s < NSTG - 1; ++s) stage(s);
-  for (int it = 0;; ++it) {
+  // one row tile; returns false behind the last one.  rs_cur / rs_nxt: the scale registers of this tile / the next one (the loop
+  // below alternates the two sets: register arrays need static names)
+  auto row_tile = [&](int it, float (&rs_cur)[WRT][WCT], float (&rs_nxt)[WRT][WCT]) -> bool {
     const int mt = slot + it * p.per;
-    if (mt >= p.ntm) break;
+    if (mt >= p.ntm) return false;
     // tile `it` landed once only the younger operations of this wave are outstanding: per later tile PD DMAs, per earlier
     // tile (its stores were issued after the DMA being waited for) PS stores -- fewer of each at the start
     // (a wave whose columns lie beyond N issues no stores at all: its count holds DMAs only)
     if (!cols_live)
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * (NSTG - 2)) : "memory");
     else if (has_rs) {
-      // + the scale loads: the set of tile it + 1 is issued in iteration it, in front of that tile's stores
-      static_assert(PD * (NSTG - 2) + (PS + RS) * (NSTG - 1) <= 63, "vmcnt range");
+      // issue order per iteration: R(it + 1), D(it + NSTG - 1), ..., S(it).  D(it) came in iteration it - NSTG + 1 behind that
+      // iteration's scale loads: younger are its stores and the (R, D, S) of the NSTG - 2 iterations since
+      static_assert((NSTG - 2) * (RS + PD + PS) + PS <= 63, "vmcnt range");
       if (it >= NSTG - 1)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * (NSTG - 2) + (PS + RS) * (NSTG - 1)) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 2) * (RS + PD + PS) + PS) : "memory");
       else if (it == 0)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * (NSTG - 2)) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * (NSTG - 2) + PS + RS) : "memory");
+      else  // (exact for it = 1, conservative up to NSTG - 2: prologue DMAs (NSTG - 2 - it) PD + it (RS + PD + PS))
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTG - 3) * PD + RS + PD + PS) : "memory");
     } else if (it >= NSTG - 1)
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * (NSTG - 2) + PS * (NSTG - 1)) : "memory");
     else if (it == 0)
@@ -203,10 +210,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(const WregP p) {
     else
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * (NSTG - 2) + PS) : "memory");
     __builtin_amdgcn_s_barrier();
+    if (has_rs) rs_issue(it + 1, rs_nxt);  // (in front of this iteration's DMAs)
     stage(it + NSTG - 1);  // into the buffer of tile it-1: every wave has consumed its fragments (they fed MFMAs already issued)
     const char* st = smem + (it % NSTG) * TILE;
 
-    if (!cols_live) continue;
+    if (!cols_live) return true;
     f32x4 acc[WRT][WCT];
 #pragma unroll
     for (int i = 0; i < WRT; ++i)
@@ -227,17 +235,16 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(const WregP p) {
       }
     }
     if (has_rs) {  // (wave-uniform; rs_cg % 16 == 0: a 16-column tile lies inside one column group)
-      // this tile's scales (issued one tile ago): younger are the previous tile's stores and this iteration's DMAs (the first
-      // tile's set is older than the whole prologue: the same count holds)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD + PS) : "memory");
+      // this tile's scales (issued at the top of the previous iteration): younger are that iteration's DMAs and stores and this
+      // iteration's scale loads and DMAs (the first tile's set is older than the whole prologue: the same count is safe)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PD + PS + RS) : "memory");
 #pragma unroll
       for (int i = 0; i < WRT; ++i)
 #pragma unroll
         for (int j = 0; j < WCT; ++j) {
-          asm volatile("" : "+v"(rsv[i][j]));
-          if (n0 + j * 16 < p.rs_ncols) acc[i][j] *= rsv[i][j] * p.rs_alpha;
+          asm volatile("" : "+v"(rs_cur[i][j]));
+          if (n0 + j * 16 < p.rs_ncols) acc[i][j] *= rs_cur[i][j] * p.rs_alpha;
         }
-      rs_issue(it + 1);  // (behind the MFMAs, in front of this tile's stores)
     }
     // ---- epilogue: wave-private strip (in-order LDS per wave: no barrier), 16-byte row-contiguous stores -----------
     const float lo = p.relu ? 0.f : -INFINITY;
@@ -274,6 +281,11 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(const WregP p) {
       else
         *dst = v;
     }
+    return true;
+  };
+  for (int it = 0;; it += 2) {
+    if (!row_tile(it, rs_a, rs_b)) break;
+    if (!row_tile(it + 1, rs_b, rs_a)) break;
   }
 }
 
@@ -311,6 +323,7 @@ int rf_gemm_wreg_try(const rf_gemm_desc& d, int64_t batch, int* rc, void* stream
   if (d.bias_mode == RF_BIAS_COL && ((uintptr_t)d.bias % 16)) return 0;
   if ((int64_t)64 * d.a_ri * 2 >= (1ll << 31)) return 0;
   const bool cs = d.c_rc > 0 || d.c_cc > 0;
+  if (d.rs && !cs) return 0;  // (the row-group scale lives in the split-C instances: the tied attention's head-major projection)
   if (cs && ((d.c_cc > 0 && (d.c_cc % 8 || d.c_co % 8)) || (d.c_rc > 0 && d.c_ro % 8))) return 0;
   WregP p;
   p.A = (const h16_t*)d.A; p.B = (const h16_t*)d.B; p.C = (h16_t*)d.C;

@@ -141,7 +141,7 @@ def gemm_takes_row_scale(M, N, K):
     """The row-group scale (`rs=` of gemm) lives in the epilogue of the register-resident-weights kernel only
     (csrc/gemm_wreg.hip: rf_gemm_wreg_try); every other kernel answers RF_EINVAL to it.  True when a plain 16-bit
     projection of this shape goes to that kernel, i.e. when a caller may fold its per-row factor into the GEMM."""
-    return (not _NO_WREG) and K in (288, 384) and M % 64 == 0 and M >= 16384 and N % 128 == 0 and N >= 256
+    return (not _NO_WREG) and K in (288, 384) and M % 64 == 0 and M >= 16384 and N % 128 == 0 and N >= 256  # (+ a split-C output)
 
 
 def linear(x, w, bias=None, *, out=None, out_dtype=None, act=L.ACT_NONE, residual=None, alpha=1.0, tile_cfg=0, ln=None):
