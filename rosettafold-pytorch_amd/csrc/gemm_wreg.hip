@@ -234,6 +234,14 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(const WregP p) {
             acc[i][j] = rf_mfma16(wf[j][s], af[i], acc[i][j], 0, 0, 0);
       }
     }
+    // MFMA results are read by VALU instructions from here on (row scale, clamp, pack): explicit wait states in the readers' path
+    // (volatile asm statements keep their order and every accumulator passes through one: no reader can move above the nops)
+    asm volatile("s_nop 7\n\ts_nop 1" : "+v"(acc[0][0]));
+#pragma unroll
+    for (int i = 0; i < WRT; ++i)
+#pragma unroll
+      for (int j = 0; j < WCT; ++j)
+        if (i + j > 0) asm volatile("" : "+v"(acc[i][j]));
     if (has_rs) {  // (wave-uniform; rs_cg % 16 == 0: a 16-column tile lies inside one column group)
       // this tile's scales (issued at the top of the previous iteration): younger are that iteration's DMAs and stores and this
       // iteration's scale loads and DMAs (the first tile's set is older than the whole prologue: the same count is safe)
@@ -247,6 +255,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wreg_kernel(const WregP p) {
         }
     }
     // ---- epilogue: wave-private strip (in-order LDS per wave: no barrier), 16-byte row-contiguous stores -----------
+    // (MFMA wait states: see behind the MFMA loop.)  The accumulators are read by VALU instructions from there on.  gfx950 does not interlock a VALU read of an MFMA destination
+    // (8 wait states behind a 16x16x32 MFMA are software's job) and hipcc's hazard recognizer pads straight-line code only: on the
+    // path that skips the row-scale block it left 6 (tools/isa_hazard_scan.py, the class of csrc/favor.hip's fv_mfma_done).  The
+    // nops sit in the readers' block, so every path passes them.
     const float lo = p.relu ? 0.f : -INFINITY;
 #pragma unroll
     for (int i = 0; i < WRT; ++i)

@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256) void se3_radial_message_kernel(const float* __
   const int tid = threadIdx.x;
   const int64_t e0 = (int64_t)blockIdx.x * 512 + tid, e1 = e0 + 256;
   const int64_t n = count[0] < capacity ? count[0] : capacity;
+  if (n <= 0) return;  // (uniform: no edge at all -- the clamped lanes below would read src[0] of an empty list)
   const bool ok0 = e0 < n, ok1 = e1 < n;
   const int64_t ea = ok0 ? e0 : 0, eb = ok1 ? e1 : 0;  // (clamped: lanes without an edge compute on edge 0 and store nothing)
   const int sa = src[ea], sb = src[eb];
