@@ -196,3 +196,58 @@ def test_resblock_and_head_dropout_active_in_training():
         R.set_compute_dtype(torch.bfloat16)
     for k in e:
         assert torch.equal(t1[k], t2[k]) and not torch.equal(t1[k], e[k]) and torch.isfinite(t1[k]).all()
+
+
+def test_msa_embedding_dropout_sits_between_the_two_additions():
+    """rf.py:114-120: dropout(emb[msa] + pe[aa_idx]) + query_enc -- subtracting the query encoding leaves zeros or the eval value / (1 - p)."""
+    p = 0.25
+    torch.manual_seed(10)
+    m = R.MsaEmbedding(21, 32, 40, p).to(DEV)
+    msa, _, aa = inputs(3, B=2, N=6, L=24)
+    ye = m(msa, aa)
+    m.train()
+    R.manual_seed(2)
+    yt = m(msa, aa)
+    q = m.query_enc.weight.detach()
+    qrow = torch.stack([q[0]] + [q[1]] * 5)[None, :, None, :]          # row 0 -> query_enc[0], the rest -> query_enc[1]
+    de, dt = ye - qrow, yt - qrow
+    dropped = dt.abs() < 1e-12
+    assert abs(dropped.float().mean().item() - p) < 0.03
+    assert torch.allclose(dt[~dropped], de[~dropped] / (1 - p), rtol=1e-5, atol=1e-6)
+
+
+def test_encoder_layer_attention_output_is_dropped_twice():
+    """Tied layer: SoftTiedAttentionOverResidues drops its projected output (rf.py:265-267) and EncoderLayer drops it again before
+    the residual add (rf.py:346): with the feed-forward switched off (zero weights) the update x_train - x is 0 with probability
+    1 - (1 - p)^2 and the eval update / (1 - p)^2 otherwise."""
+    p = 0.2
+    torch.manual_seed(12)
+    layer = R.EncoderLayer(d_msa=96, d_ff=384, n_heads=12, p_dropout=p, tied=True, return_att=True).to(DEV)
+    with torch.no_grad():
+        layer.ff.fn[1].net[3].weight.zero_()
+        layer.ff.fn[1].net[3].bias.zero_()
+        layer.attn.poswise_weight.p_dropout = 0.0     # (keep the position weights: their dropout changes the attention itself)
+    x = rn(1, 8, 32, 96)
+    R.set_compute_dtype(torch.float32)
+    try:
+        oe, _ = layer(x)
+        layer.train()
+        R.manual_seed(4)
+        ot, _ = layer(x)
+    finally:
+        R.set_compute_dtype(torch.bfloat16)
+    de, dt = oe - x, ot - x
+    dropped = dt.abs() < 1e-12
+    assert abs(dropped.float().mean().item() - (1 - (1 - p) ** 2)) < 0.03
+    assert torch.allclose(dt[~dropped], de[~dropped] / (1 - p) ** 2, rtol=1e-4, atol=1e-6)
+
+
+def test_three_track_msa_update_with_pair_keeps_the_reference_hard_coded_probability():
+    """rf.py:1015, 1101: MsaUpdateWithPair of the three-track / final blocks is built with p_dropout = 0.1 whatever the model's
+    p_dropout; PairUpdateWithMsa always with its default 0.1 (rf.py:995-1000)."""
+    model = R.RoseTTAFold(p_dropout=0.0, **CFG)
+    for blk in list(model.three_track_blocks) + [model.final_block]:
+        assert all(l.p_dropout == 0.1 for l in blk.msa_update_with_pair.encoder_layers)
+    assert all(l.p_dropout == 0.0 for l in model.two_track_blocks[0].msa_update_with_pair.encoder_layers)
+    import torch.nn as nn
+    assert all(d.p == 0.1 for d in model.two_track_blocks[0].pair_update_with_msa.modules() if isinstance(d, nn.Dropout))
