@@ -254,6 +254,32 @@ int rf_instnorm_apply(const void* x, int x_dtype, const void* sums, const float*
                       const float* residual, int act, void* y, int y_dtype, void* y2, int y2_dtype, int B, int64_t HW,
                       int C, void* stream);
 
+/* ---- operand conditioning of the 16-bit modes (csrc/condition.hip): exact algebra, the function computed is unchanged ----
+ * At random init every stream is a large per-sample constant vector plus a position-dependent part 10-30x smaller, and the
+ * InstanceNorms (rf.py:453,457; resnet.py:29,39,63) keep only the latter; an operand rounded to 16 bits WITH the constant is
+ * 10-30x coarser than the information that survives.  PairUpdateWithMsa (rf.py:476-498), PredictionHead (rf.py:1130-1172)
+ * and the structure track's embeddings remove the constant before the rounding and add W * constant back in fp32:
+ *   W (x - m) + (b + W m) == W x + b;   conv3x3(x - m) + [taps outside the picture] == conv3x3(x) - const (InstanceNorm drops it).
+ * mean[b,c] = sums[b,c,0] / HW from the sums of rf_instnorm_stats (fp32 [B,C]). */
+int rf_instnorm_mean(const void* sums, float* mean, int B, int64_t HW, int C, void* stream);
+/* y[b,p,c] = x[b,p,c] - mean[b,c]; x fp32 [B,HW,C], y fp32 or the 16-bit type (may alias x when fp32); C % 4 == 0, 16-byte
+ * aligned pointers. */
+int rf_center_apply(const float* x, const float* mean, void* y, int y_dtype, int B, int64_t HW, int C, void* stream);
+/* small tensors: mean[b,c] = mean over the R rows of x[b] (fp32 [B,R,C]) and x -= mean, in place (one block per sample). */
+int rf_center_rows(float* x, float* mean, int B, int R, int C, void* stream);
+/* the constant's way through a weight matrix (w fp32 [N, ldw]; mean fp32 [B,K]; bias fp32 [N] or NULL):
+ *   sum_seg != 0: out[b,n]   = bias[n] + sum_{s<nseg} sum_{k<K} w[n, k0 + s*seg_stride + k] * mean[b,k]
+ *   sum_seg == 0: out[b,s,n] = bias[n] +                sum_{k<K} w[n, k0 + s*seg_stride + k] * mean[b,k]   (e.g. the 9 taps
+ *   of a 3x3 convolution stored [Co, 9*Ci]: nseg 9, seg_stride Ci). */
+int rf_fold_mean(const float* w, int64_t ldw, int k0, int K, int nseg, int64_t seg_stride, int sum_seg, const float* mean,
+                 const float* bias, float* out, int B, int N, void* stream);
+/* 3x3 'same' (zero-padded) convolution of a centred picture: y[b,i,j,:] -= sum of taps[b, kh*3+kw, :] over the taps whose
+ * source pixel (i+(kh-1)d, j+(kw-1)d) lies outside the picture, so that y == conv3x3(x) - (sum of all taps) everywhere.
+ * y NHWC fp32 or 16-bit, in place; taps fp32 [B,9,C] (rf_fold_mean); edges: which sides of this block are sides of the picture
+ * (1 top | 2 bottom | 4 left | 8 right; 15 for a whole picture, a row block of a sharded picture has neighbours). */
+int rf_conv3x3_border_fix(void* y, int y_dtype, const float* taps, int B, int H, int W, int C, int dilation, int edges,
+                          void* stream);
+
 /* MsaEmbedding (rf.py:106-120): y[b,n,l,:] = emb[msa[b,n,l]] + pe[aa_idx[b,l]] + qenc[n==0 ? 0 : 1]; fp32 out. */
 int rf_msa_embed(const int64_t* msa, const int64_t* aa_idx, const float* emb, const float* pe, const float* qenc,
                  float* y, int B, int N, int L, int D, void* stream);

@@ -62,6 +62,11 @@ PROTOTYPES = {
     "rf_instnorm_ws_bytes": [i32, i64, i32],  # returns int64
     "rf_instnorm_stats": [vp, i32, vp, i32, i64, i32, vp, i64, vp],
     "rf_instnorm_apply": [vp, i32, vp, vp, vp, f32, vp, i32, vp, i32, vp, i32, i32, i64, i32, vp],
+    "rf_instnorm_mean": [vp, vp, i32, i64, i32, vp],
+    "rf_center_apply": [vp, vp, vp, i32, i32, i64, i32, vp],
+    "rf_center_rows": [vp, vp, i32, i32, i32, vp],
+    "rf_fold_mean": [vp, i64, i32, i32, i32, i64, i32, vp, vp, vp, i32, i32, vp],
+    "rf_conv3x3_border_fix": [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
     "rf_msa_embed": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "rf_pair_embed": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rf_copy4d": [vp, i32, C.POINTER(I64x4), vp, i32, C.POINTER(I64x4), C.POINTER(I64x4), vp],

@@ -1,0 +1,216 @@
+// Operand conditioning of the 16-bit modes (exact algebra, no change of the function computed).
+//
+// At random init every stream of the model is a large per-sample constant vector (the "common mode": embedding biases and
+// LayerNorm offsets, the same at every position) plus a position-dependent part 10-30x smaller, and the network's
+// InstanceNorms (rf.py:453,457; resnet.py:29,39,63) keep only the latter.  A 16-bit operand that still carries the constant is
+// rounded relative to the constant, i.e. 10-30x coarser than the information the next InstanceNorm keeps.  These kernels
+// remove the constant from an operand BEFORE it is rounded and account for it exactly on the fp32 side of the GEMM:
+//     W (x - m) + (b + W m)  ==  W x + b                     (rf_center_rows / rf_center_apply + rf_fold_mean)
+//     conv3x3(x - m) - sum over the taps that fall outside the picture of W_tap m  ==  conv3x3(x) - sum over all taps of W_tap m
+//                                                             (rf_conv3x3_border_fix; the right side differs from conv3x3(x)
+//                                                              by a per-channel constant, which the InstanceNorm removes)
+// tools/precision_probe.py --pum-sweep measures what each site costs without it (PairUpdateWithMsa, rf.py:430-498: the tiled
+// 1-D features 1.3e-2, the first convolution's input 9.7e-3 and output 7.3e-3 of the fp16 mode's 2.0e-2 logits gap).
+#include "common.h"
+
+#define RF_CHECK_DT(dt) \
+  if ((dt) != RF_F32 && (dt) != RF_H16) return RF_EINVAL
+
+static inline unsigned cdiv(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ---- mean[b, c] = sums[b, c, 0] / HW  (sums of rf_instnorm_stats) ----------------------------------------------------------
+__global__ __launch_bounds__(256) void sums_mean_kernel(const double* sums, float* mean, double inv, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) mean[i] = (float)(sums[2 * (int64_t)i] * inv);
+}
+
+extern "C" int rf_instnorm_mean(const void* sums, float* mean, int B, int64_t HW, int C, void* stream) {
+  if (!sums || !mean || B <= 0 || C <= 0 || HW <= 0) return RF_EINVAL;
+  const int n = B * C;
+  hipLaunchKernelGGL(sums_mean_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const double*)sums, mean,
+                     1.0 / (double)HW, n);
+  return rf_launch_status();
+}
+
+// ---- y[b, p, c] = x[b, p, c] - mean[b, c]   (x fp32 NHWC, y fp32 or the 16-bit type; C % 4 == 0) ---------------------------
+// The grid stride is a multiple of the C / 4 chunks of a pixel, so a thread keeps ONE channel chunk: its four means live in
+// registers and the loop is a 16-byte load, four subtractions and one 8- or 16-byte store.
+template <bool H16OUT>
+__global__ __launch_bounds__(256) void center_apply_kernel(const float4* __restrict__ x, const float* __restrict__ mean,
+                                                           void* __restrict__ y, int64_t chunks, int C4) {
+  const int b = blockIdx.y;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= chunks) return;
+  const int c4 = (int)(e % C4);
+  const float4 m = ((const float4*)(mean + (int64_t)b * C4 * 4))[c4];
+  const float4* xb = x + (int64_t)b * chunks;
+  for (; e < chunks; e += stride) {
+    float4 v = xb[e];
+    v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w;
+    if (H16OUT) {
+      uint2 o;
+      o.x = rf_pack2_h16(v.x, v.y);
+      o.y = rf_pack2_h16(v.z, v.w);
+      ((uint2*)y)[(int64_t)b * chunks + e] = o;
+    } else {
+      ((float4*)y)[(int64_t)b * chunks + e] = v;
+    }
+  }
+}
+
+extern "C" int rf_center_apply(const float* x, const float* mean, void* y, int y_dtype, int B, int64_t HW, int C,
+                               void* stream) {
+  RF_CHECK_DT(y_dtype);
+  if (!x || !mean || !y || B <= 0 || HW <= 0 || C <= 0 || C % 4 != 0) return RF_EINVAL;
+  if (((uintptr_t)x % 16) || ((uintptr_t)mean % 16) || ((uintptr_t)y % 16)) return RF_EINVAL;
+  const int C4 = C / 4;
+  const int64_t chunks = HW * C4;
+  unsigned gx = min(cdiv(chunks, 256), 2048u);
+  {  // grid stride (gx * 256) a multiple of C4
+    unsigned g = (unsigned)C4, r = 256u % (unsigned)C4;
+    while (r) { const unsigned t = g % r; g = r; r = t; }   // gcd(C4, 256)
+    const unsigned m = (unsigned)C4 / g;
+    gx = gx >= m ? gx / m * m : m;
+  }
+  if (y_dtype == RF_F32)
+    hipLaunchKernelGGL(center_apply_kernel<false>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, (const float4*)x, mean, y, chunks, C4);
+  else
+    hipLaunchKernelGGL(center_apply_kernel<true>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, (const float4*)x, mean, y, chunks, C4);
+  return rf_launch_status();
+}
+
+// ---- small tensors: mean over the R rows of x[b] (fp32 [B, R, C]) and x -= mean in place ----------------------------------
+// One block per sample; thread t owns channel t % C of the rows t / C, t / C + 256 / C, ... (C divides 256) or channels
+// t, t + 256, ... of every row (any other C); fixed summation order, no atomics.
+__global__ __launch_bounds__(256) void center_rows_kernel(float* __restrict__ x, float* __restrict__ mean, int R, int C) {
+  __shared__ float part[256];
+  __shared__ float mu[256];
+  float* xb = x + (int64_t)blockIdx.x * R * C;
+  const int t = threadIdx.x;
+  if (C <= 256 && 256 % C == 0) {
+    const int c = t % C, g = t / C, G = 256 / C;
+    float s = 0.f;
+    for (int r = g; r < R; r += G) s += xb[(int64_t)r * C + c];
+    part[t] = s;
+    __syncthreads();
+    if (t < C) {
+      float a = 0.f;
+      for (int k = 0; k < G; ++k) a += part[k * C + t];
+      a /= (float)R;
+      mu[t] = a;
+      mean[(int64_t)blockIdx.x * C + t] = a;
+    }
+    __syncthreads();
+    const float m = mu[c];
+    for (int r = g; r < R; r += G) xb[(int64_t)r * C + c] -= m;
+  } else {
+    for (int c = t; c < C; c += 256) {
+      float s = 0.f;
+      for (int r = 0; r < R; ++r) s += xb[(int64_t)r * C + c];
+      s /= (float)R;
+      mean[(int64_t)blockIdx.x * C + c] = s;
+      for (int r = 0; r < R; ++r) xb[(int64_t)r * C + c] -= s;
+    }
+  }
+}
+
+extern "C" int rf_center_rows(float* x, float* mean, int B, int R, int C, void* stream) {
+  if (!x || !mean || B <= 0 || R <= 0 || C <= 0) return RF_EINVAL;
+  hipLaunchKernelGGL(center_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, mean, R, C);
+  return rf_launch_status();
+}
+
+// ---- the constant's way through a weight matrix --------------------------------------------------------------------------
+// sum_seg != 0:  out[b, n]    = (bias ? bias[n] : 0) + sum_{s < nseg} sum_{k < K} w[n, k0 + s * seg_stride + k] * mean[b, k]
+// sum_seg == 0:  out[b, s, n] = (bias ? bias[n] : 0) +                 sum_{k < K} w[n, k0 + s * seg_stride + k] * mean[b, k]
+// One wave per output element, lanes over k (coalesced rows of w), fixed-order butterfly reduction.
+__global__ __launch_bounds__(256) void fold_mean_kernel(const float* __restrict__ w, int64_t ldw, int k0, int K, int nseg,
+                                                        int64_t seg_stride, int sum_seg, const float* __restrict__ mean,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int N,
+                                                        int64_t items) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= items) return;   // (whole waves leave together)
+  const int n = (int)(item % N);
+  const int so = sum_seg ? 1 : nseg;
+  const int s_out = (int)((item / N) % so);
+  const int b = (int)(item / ((int64_t)N * so));
+  const float* mb = mean + (int64_t)b * K;
+  const float* wr = w + (int64_t)n * ldw + k0;
+  float acc = 0.f;
+  const int s0 = sum_seg ? 0 : s_out, s1 = sum_seg ? nseg : s_out + 1;
+  for (int s = s0; s < s1; ++s)
+    for (int k = lane; k < K; k += 64) acc += wr[s * seg_stride + k] * mb[k];
+  acc = wave_sum(acc);
+  if (lane == 0) out[item] = acc + (bias ? bias[n] : 0.f);
+}
+
+extern "C" int rf_fold_mean(const float* w, int64_t ldw, int k0, int K, int nseg, int64_t seg_stride, int sum_seg,
+                            const float* mean, const float* bias, float* out, int B, int N, void* stream) {
+  if (!w || !mean || !out || B <= 0 || N <= 0 || K <= 0 || nseg <= 0 || k0 < 0 || seg_stride < 0) return RF_EINVAL;
+  if (k0 + (int64_t)(nseg - 1) * seg_stride + K > ldw) return RF_EINVAL;
+  const int64_t items = (int64_t)B * N * (sum_seg ? 1 : nseg);
+  hipLaunchKernelGGL(fold_mean_kernel, dim3((unsigned)cdiv(items, 4)), dim3(256), 0, (hipStream_t)stream, w, ldw, k0, K, nseg,
+                     seg_stride, sum_seg, mean, bias, out, N, items);
+  return rf_launch_status();
+}
+
+// ---- 3x3 'same' convolution of a centred picture: what the zero padding owes at the border --------------------------------
+// y[b, i, j, :] -= sum over the taps (kh, kw) whose source pixel (i + (kh-1) d, j + (kw-1) d) lies outside the picture of
+// taps[b, kh*3 + kw, :]   (taps[b, t, o] = sum_c W[o, c, t] m[b, c], rf_fold_mean on the [Co, 9 Ci] weight).  `edges` names the
+// sides of THIS block that are sides of the picture (1 top, 2 bottom, 4 left, 8 right; a row block of a sharded picture has
+// neighbours above / below).  One block per border pixel, threads over the channels.
+__global__ __launch_bounds__(256) void conv3x3_border_fix_kernel(void* y, int y_dt, const float* __restrict__ taps, int H, int W,
+                                                                 int C, int d, int edges) {
+  const int b = blockIdx.y;
+  int p = blockIdx.x, i, j;
+  // border pixels in order: the first d rows, the last d rows (each only if that side is an edge), then for the rows between
+  // the first d and the last d columns
+  const int top = (edges & 1) ? d : 0, bot = (edges & 2) ? d : 0;
+  if (p < top * W) {
+    i = p / W; j = p % W;
+  } else if (p < (top + bot) * W) {
+    p -= top * W;
+    i = H - bot + p / W; j = p % W;
+  } else {
+    p -= (top + bot) * W;
+    const int lw = (edges & 4) ? d : 0, rw = (edges & 8) ? d : 0;
+    const int per = lw + rw;
+    i = top + p / per;
+    const int jj = p % per;
+    j = jj < lw ? jj : W - rw + (jj - lw);
+  }
+  bool out_r[3], out_c[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int ii = i + (k - 1) * d, jj = j + (k - 1) * d;
+    out_r[k] = (ii < 0 && (edges & 1)) || (ii >= H && (edges & 2));
+    out_c[k] = (jj < 0 && (edges & 4)) || (jj >= W && (edges & 8));
+  }
+  const float* tb = taps + (int64_t)b * 9 * C;
+  const int64_t base = (((int64_t)b * H + i) * W + j) * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float corr = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+        if (out_r[kh] || out_c[kw]) corr += tb[(kh * 3 + kw) * C + c];
+    st(y, y_dt, base + c, ld(y, y_dt, base + c) - corr);
+  }
+}
+
+extern "C" int rf_conv3x3_border_fix(void* y, int y_dtype, const float* taps, int B, int H, int W, int C, int dilation,
+                                     int edges, void* stream) {
+  RF_CHECK_DT(y_dtype);
+  if (!y || !taps || B <= 0 || H <= 0 || W <= 0 || C <= 0 || dilation <= 0 || (edges & ~15)) return RF_EINVAL;
+  const int d = dilation;
+  const int top = (edges & 1) ? d : 0, bot = (edges & 2) ? d : 0, lw = (edges & 4) ? d : 0, rw = (edges & 8) ? d : 0;
+  if (top + bot > H || lw + rw > W) return RF_EINVAL;   // (pictures narrower than the stencil: not a shape of the model)
+  const int64_t nb = (int64_t)(top + bot) * W + (int64_t)(H - top - bot) * (lw + rw);
+  if (nb == 0) return 0;
+  hipLaunchKernelGGL(conv3x3_border_fix_kernel, dim3((unsigned)nb, B), dim3(256), 0, (hipStream_t)stream, y, y_dtype, taps, H, W, C,
+                     d, edges);
+  return rf_launch_status();
+}

@@ -45,6 +45,9 @@ class _Runtime:
     # PredictionHead: remove the per-(sample, channel) mean over the picture from the projected pair tensor before it is rounded
     # to the 16-bit operand type (PredictionHead.run; RF_HEAD_CENTER=0 restores the plain cast)
     head_center = bool(int(__import__("os").environ.get("RF_HEAD_CENTER", "1")))
+    # Operand conditioning of the 16-bit modes (csrc/condition.hip; exact algebra): PairUpdateWithMsa's tiled 1-D features and its
+    # first convolution see operands with the per-sample constant removed.  RF_CONDITION=0: the plain form (ablation / probes).
+    condition = bool(int(__import__("os").environ.get("RF_CONDITION", "1")))
     # SE(3) radial MLPs: last Linear inside the message kernel (csrc/se3.hip: rf_se3_radial_message); RF_SE3_UNFUSED=1 writes the
     # radial outputs with a K = 32 GEMM and reads them back (round-3 path, kept for A/B timing and as the form for unusual shapes)
     se3_fused_radial = not bool(int(__import__("os").environ.get("RF_SE3_UNFUSED", "0")))
@@ -1104,6 +1107,23 @@ class PairUpdateWithMsa(RFModule):
             ops.copy4d(src, (N * Lr * P, P, 1, Lr * P), dst, (Lr * P * Np, P * Np, Np, 1), (B, Lr, P, N))
         return msa1d, xt, yt, Np
 
+    # ---- operand conditioning of the 16-bit modes (csrc/condition.hip; tools/precision_probe.py --pum-sweep) ------------------
+    # At random init the 1-D features and the projected feature tensor are a per-sample constant plus a part ~20x smaller that
+    # varies over the picture, and the ResNet's InstanceNorms keep only the latter: rounded to 16 bits WITH the constant, the
+    # tiled 1-D features (1.3e-2), the first convolution's input (9.7e-3) and its output (7.3e-3) were 1.8e-2 of the fp16 mode's
+    # 2.0e-2 logits gap at the benchmarked depth.  Both constants are removed before the rounding and carried in fp32:
+    #   W (f - m) + (b + W m) == W f + b                           (the 1-D features' mean through the projection's bias)
+    #   conv3x3(x - c) + [border terms] == conv3x3(x) - sum_taps W_tap c   (a per-channel constant: the InstanceNorm drops it)
+    def _center_1d(self, msa1d, bias):
+        P, Dp = self.d_proj, self.d_pair
+        w32 = self.cached("f_f32", lambda: self.resnet[0].weight.detach().float().contiguous())
+        return ops.fold_mean(w32, ops.center_rows(msa1d), bias, k0=Dp, nseg=2, seg_stride=2 * P)
+
+    def _conv_taps(self, conv, cx):
+        Co, Ci = conv.weight.shape[:2]
+        w32 = self.cached("c1_f32", lambda: conv.weight.detach().permute(0, 2, 3, 1).reshape(Co, 9 * Ci).float().contiguous())
+        return ops.fold_mean(w32, cx, None, nseg=9, seg_stride=Ci, sum_seg=False)   # [B, 9, Co]
+
     def run_rows(self, msa, pair_rows, att, row_group):
         """run() for a block of pair rows (pair-track row-block sharding, shard.pair_update_with_msa_row_sharded): msa
         [B,N,L,D] and att [B,L,L,H] are replicated, pair_rows fp32 [B,h,L,Dp] are this rank's rows shard_range(L, world, rank).
@@ -1125,6 +1145,10 @@ class PairUpdateWithMsa(RFModule):
                         (h * P * Np, P * Np, Np, 1), (B, h, P, Np), x_off=r0 * P * Np)
         coevol = self.outer_product_mean.run_rows(xr, yt, Np)  # fp32 [B,h,L,Dp]
         ln(self.ln_coevol_feat, coevol, out=feat, out_ld=Kf, out_off=0)
+        cond = RT.condition and ops.is_h16(T())
+        bias = _f(self.resnet[0].bias)
+        if cond:   # (the mean over ALL positions: msa is replicated, every rank folds the same constant)
+            bias_b = self._center_1d(msa1d, bias)
         # feat[b,i,j, Dp + c] = msa1d[b, r0 + i, c] ; feat[b,i,j, Dp + 2P + c] = msa1d[b, j, c]   (rf_tile_1d_feats on a block)
         fs = (h * Lr * Kf, Lr * Kf, Kf, 1)
         ops.copy4d(msa1d, (Lr * 2 * P, 2 * P, 0, 1), feat, fs, (B, h, Lr, 2 * P), x_off=r0 * 2 * P, y_off=Dp)
@@ -1132,14 +1156,28 @@ class PairUpdateWithMsa(RFModule):
         ln(self.ln_pair, pair_rows, out=feat, out_ld=Kf, out_off=Dp + 4 * P)
         H = att.shape[-1]
         ops.copy4d(att.contiguous(), (Lr * Lr * H, Lr * H, H, 1), feat, fs, (B, h, Lr, H), x_off=r0 * Lr * H, y_off=2 * Dp + 4 * P)
-        x = ops.linear(feat, self.wt("f", self.resnet[0], kpad=Kf), _f(self.resnet[0].bias), out_dtype=F32)
         blk = self.resnet[1].fn
         kw = {"row_group": row_group, "rows_global": Lr}
+        if cond:
+            x = torch.empty(B, h, Lr, Dp, device=dev, dtype=F32)
+            for b in range(B):
+                ops.linear(feat[b], self.wt("f", self.resnet[0], kpad=Kf), bias_b[b], out=x[b])
+            cx = ops.channel_mean(x, **kw)
+            taps = self._conv_taps(blk[1], cx)
+            n_r, r_ = shard.group_size(row_group), shard.group_rank(row_group)
+            edges = 12 | (1 if r_ == 0 else 0) | (2 if r_ == n_r - 1 else 0)   # left | right, top / bottom on the outer ranks
+        else:
+            x = ops.linear(feat, self.wt("f", self.resnet[0], kpad=Kf), bias, out_dtype=F32)
         if B == 1:   # one picture: pre-haloed buffers, only the halo rows move (see ResBlock2D._run_rows_b1)
             xh = shard.haloed_buffer(h, Lr, Dp, 1, dev, T())
-            ops.axpby(x, 1.0, None, 0.0, shard.interior(xh, 1))
+            if cond:
+                ops.center_apply(x, cx, out=shard.interior(xh, 1))
+            else:
+                ops.axpby(x, 1.0, None, 0.0, shard.interior(xh, 1))
             shard.exchange_row_halos_inplace(xh, 1, row_group)
             y = conv3x3(self, "c1", blk[1], xh, 1)
+            if cond:
+                ops.conv3x3_border_fix(shard.interior(y, 1), taps, 1, edges)
             yh = shard.haloed_buffer(h, Lr, Dp, 1, dev, T())
             ops.instnorm(shard.interior(y, 1), _f(blk[2].weight), _f(blk[2].bias), eps=blk[2].eps, act=L.ACT_ELU,
                          out=shard.interior(yh, 1), **kw)
@@ -1149,7 +1187,10 @@ class PairUpdateWithMsa(RFModule):
                                   act=L.ACT_ELU, out_dtype=F32, **kw)
             return out
         conv = lambda key, c, t: shard.drop_row_halos(conv3x3(self, key, c, shard.exchange_row_halos(t, 1, row_group), 1), 1)  # noqa: E731
-        y = conv("c1", blk[1], ops.cast(x, T()))
+        if cond:
+            y = ops.conv3x3_border_fix(conv("c1", blk[1], ops.center_apply(x, cx, out_dtype=T())), taps, 1, edges)
+        else:
+            y = conv("c1", blk[1], ops.cast(x, T()))
         y, _ = ops.instnorm(y, _f(blk[2].weight), _f(blk[2].bias), eps=blk[2].eps, act=L.ACT_ELU, out_dtype=T(), **kw)
         y = conv("c2", blk[5], y)
         out, _ = ops.instnorm(y, _f(blk[6].weight), _f(blk[6].bias), eps=blk[6].eps, residual=x, act=L.ACT_ELU,
@@ -1174,13 +1215,25 @@ class PairUpdateWithMsa(RFModule):
         else:
             coevol = self.outer_product_mean.run(xt, yt, Np)  # fp32 [B,L,L,Dp]
             ln(self.ln_coevol_feat, coevol, out=feat, out_ld=Kf, out_off=0)
+        H = att.shape[-1]
+        blk = self.resnet[1].fn
+        cond = RT.condition and ops.is_h16(T())
+        bias = _f(self.resnet[0].bias)
+        if cond:
+            bias_b = self._center_1d(msa1d, bias)   # msa1d -= its mean over the positions; [B, Dp] bias that carries W * mean
         ops.tile_1d_feats(msa1d, feat, Kf, Dp, B, Lr, 2 * P)
         ln(self.ln_pair, pair, out=feat, out_ld=Kf, out_off=Dp + 4 * P)
-        H = att.shape[-1]
         ops.copy4d(att.contiguous(), (0, 0, H, 1), feat, (0, 0, Kf, 1), (1, 1, B * Lr * Lr, H), y_off=2 * Dp + 4 * P)
-        x = ops.linear(feat, self.wt("f", self.resnet[0], kpad=Kf), _f(self.resnet[0].bias), out_dtype=F32)
-        blk = self.resnet[1].fn
-        y = conv3x3(self, "c1", blk[1], ops.cast(x, T()), 1)
+        if cond:
+            x = torch.empty(B, Lr, Lr, Dp, device=dev, dtype=F32)
+            for b in range(B):
+                ops.linear(feat[b], self.wt("f", self.resnet[0], kpad=Kf), bias_b[b], out=x[b])
+            cx = ops.channel_mean(x)
+            y = conv3x3(self, "c1", blk[1], ops.center_apply(x, cx, out_dtype=T()), 1)
+            ops.conv3x3_border_fix(y, self._conv_taps(blk[1], cx), 1)
+        else:
+            x = ops.linear(feat, self.wt("f", self.resnet[0], kpad=Kf), bias, out_dtype=F32)
+            y = conv3x3(self, "c1", blk[1], ops.cast(x, T()), 1)
         y, _ = ops.instnorm(y, _f(blk[2].weight), _f(blk[2].bias), eps=blk[2].eps, act=L.ACT_ELU, out_dtype=T())
         if self.training:
             dropout_(y, _p(blk[4]))   # rf.py:455
@@ -1541,11 +1594,11 @@ class InitialCoordGenerationWithMsaAndPair(RFModule):
 
     def run(self, msa, pair, seq_onehot, aa_idx):
         B, Lr, _, Dp = pair.shape
+        Ke = pad8(Dp + 1)
+        ein = ops.zeros(B, Lr, Lr, Ke, device=pair.device, dtype=T())
         nin, Kp = _node_input(self, msa, seq_onehot)
         node = ops.linear(nin, self.wt("n", self.node_embed[0], kpad=Kp), _f(self.node_embed[0].bias), out_dtype=F32,
                           act=L.ACT_ELU)
-        Ke = pad8(Dp + 1)
-        ein = ops.zeros(B, Lr, Lr, Ke, device=pair.device, dtype=T())
         ln(self.ln_pair, pair, out=ein, out_ld=Ke)
         ops.seqsep_feature(aa_idx.contiguous(), ein, Ke, Dp)  # clamp(sign(d) log(|d|+1), 0, 5.5), rf.py:746-749
         edge = ops.linear(ein, self.wt("e", self.edge_embed[0], kpad=Ke), _f(self.edge_embed[0].bias), act=L.ACT_ELU)
@@ -1684,16 +1737,23 @@ class PredictionHead(RFModule):
         transposed sub-blocks from the other ranks, the ResNets exchange halo rows and InstanceNorm sums; returns the same rows
         of the logit maps."""
         B, h, Lr, Cc = pair.shape
-        x = ops.linear(ln(self.proj[0], pair), self.wt("p", self.proj[1]), _f(self.proj[1].bias), out_dtype=F32)
-        if self.training:
-            dropout_(x, _p(self.proj[2]))   # rf.py:1138
-        if RT.head_center and ops.is_h16(T()) and row_group is None:
-            # Operand conditioning for the 16-bit modes (exact in exact arithmetic): every ResNet starts conv1x1 (no bias) ->
-            # InstanceNorm (resnet.py:57-60), which is invariant to a per-channel constant of the conv's input, and the mean over
-            # the picture of 0.5 (x + x^T) is the mean of x.  At random init that constant is ~19x the part that varies over the
-            # picture (tools/precision_probe.py: the first InstanceNorm amplifies a white input error 19x), so rounding x to 16
-            # bits AFTER removing it makes the rounding relative to the information the head actually uses.
-            ops.center_channels(x)
+        kwc = {} if row_group is None else {"row_group": row_group, "rows_global": Lr}
+        # Operand conditioning for the 16-bit modes (exact in exact arithmetic): every ResNet starts conv1x1 (no bias) ->
+        # InstanceNorm (resnet.py:57-60), which is invariant to a per-channel constant of the conv's input, and the mean over
+        # the picture of 0.5 (x + x^T) is the mean of x.  At random init that constant is ~19x the part that varies over the
+        # picture (tools/precision_probe.py: the first InstanceNorm amplifies a white input error 19x), so x is rounded to 16
+        # bits AFTER removing it -- and so is the projection's own operand LayerNorm(pair) (the other 6e-3 of the fp16 mode's
+        # logits gap): W (t - mean t) is the projection minus ITS mean over the picture, bias and all.
+        cond = RT.head_center and ops.is_h16(T())
+        if cond and not self.training:
+            t = ln(self.proj[0], pair, out_dtype=F32)
+            x = ops.linear(ops.center_apply(t, ops.channel_mean(t, **kwc), out_dtype=T()), self.wt("p", self.proj[1]), None, out_dtype=F32)
+        else:
+            x = ops.linear(ln(self.proj[0], pair), self.wt("p", self.proj[1]), _f(self.proj[1].bias), out_dtype=F32)
+            if self.training:
+                dropout_(x, _p(self.proj[2]))   # rf.py:1138
+            if cond:
+                ops.center_apply(x, ops.channel_mean(x, **kwc))
         if row_group is None:
             xt = torch.empty_like(x)
             ops.copy4d(x, (Lr * Lr * Cc, Cc, Lr * Cc, 1), xt, (Lr * Lr * Cc, Lr * Cc, Cc, 1), (B, Lr, Lr, Cc))

@@ -401,6 +401,71 @@ def center_channels(x, out=None):
     return y
 
 
+def channel_mean(x, row_group=None, rows_global=None):
+    """fp32 [B, C] mean over the picture of NHWC x (rf_instnorm_stats + rf_instnorm_mean; row_group / rows_global as in
+    instnorm: x is a block of rows of a sharded picture, the sums are all-reduced)."""
+    B, H, W, Cc = x.shape
+    _need_cuda(x)
+    sums = torch.empty(B * Cc * 2, device=x.device, dtype=torch.float64)
+    ws_bytes = int(lib.rf_instnorm_ws_bytes(B, H * W, Cc))
+    ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+    check(lib.rf_instnorm_stats(ptr(x), dcode(x.dtype), ptr(sums), B, H * W, Cc, ptr(ws), ws_bytes, stream()), "rf_instnorm_stats")
+    count = H * W
+    if row_group is not None:
+        from . import shard
+        shard.all_reduce_sum(sums, row_group)
+        count = rows_global * W
+    mean = torch.empty(B, Cc, device=x.device, dtype=F32)
+    check(lib.rf_instnorm_mean(ptr(sums), ptr(mean), B, count, Cc, stream()), "rf_instnorm_mean")
+    return mean
+
+
+def center_apply(x, mean, out=None, out_dtype=None):
+    """out[b, ..., c] = x[b, ..., c] - mean[b, c]; x fp32 [B, ..., C] contiguous, out fp32 (default: in place) or 16-bit."""
+    B, Cc = x.shape[0], x.shape[-1]
+    y = out if out is not None else (x if out_dtype in (None, F32) else torch.empty(x.shape, device=x.device, dtype=out_dtype))
+    _need_cuda(x, mean, y)
+    if x.dtype != F32 or not x.is_contiguous() or not y.is_contiguous() or tuple(y.shape) != tuple(x.shape) or tuple(mean.shape) != (B, Cc):
+        raise ValueError("center_apply: x fp32 contiguous, out of x's shape and contiguous, mean [B, C]")
+    check(lib.rf_center_apply(ptr(x), ptr(mean), ptr(y), dcode(y.dtype), B, x.numel() // (B * Cc), Cc, stream()), "rf_center_apply")
+    return y
+
+
+def center_rows(x):
+    """x fp32 [B, R, C] (small): x -= mean over R, in place; returns the fp32 [B, C] mean."""
+    B, R, Cc = x.shape
+    _need_cuda(x)
+    if x.dtype != F32 or not x.is_contiguous():
+        raise ValueError("center_rows: fp32 contiguous [B, R, C]")
+    mean = torch.empty(B, Cc, device=x.device, dtype=F32)
+    check(lib.rf_center_rows(ptr(x), ptr(mean), B, R, Cc, stream()), "rf_center_rows")
+    return mean
+
+
+def fold_mean(w, mean, bias=None, *, k0=0, nseg=1, seg_stride=0, sum_seg=True):
+    """The constant's way through a weight matrix (rf_fold_mean): w fp32 [N, ldw], mean fp32 [B, K] ->
+    sum_seg: [B, N] = bias + sum_s w[:, k0 + s*seg_stride : +K] @ mean ; else [B, nseg, N], one product per segment."""
+    N, ldw = w.shape
+    B, K = mean.shape
+    _need_cuda(w, mean, bias)
+    if w.dtype != F32 or mean.dtype != F32 or not w.is_contiguous() or not mean.is_contiguous():
+        raise ValueError("fold_mean: fp32 contiguous operands")
+    out = torch.empty((B, N) if sum_seg else (B, nseg, N), device=w.device, dtype=F32)
+    check(lib.rf_fold_mean(ptr(w), ldw, k0, K, nseg, seg_stride, 1 if sum_seg else 0, ptr(mean), ptr(bias), ptr(out), B, N,
+                           stream()), "rf_fold_mean")
+    return out
+
+
+def conv3x3_border_fix(y, taps, dilation=1, edges=15):
+    """y NHWC (fp32 / 16-bit, in place) -= the taps [B, 9, C] that fall outside the picture (rf_conv3x3_border_fix)."""
+    B, H, W, Cc = y.shape
+    _need_cuda(y, taps)
+    if not y.is_contiguous() or tuple(taps.shape) != (B, 9, Cc) or taps.dtype != F32 or not taps.is_contiguous():
+        raise ValueError("conv3x3_border_fix: y contiguous NHWC, taps fp32 [B, 9, C]")
+    check(lib.rf_conv3x3_border_fix(ptr(y), dcode(y.dtype), ptr(taps), B, H, W, Cc, dilation, edges, stream()), "rf_conv3x3_border_fix")
+    return y
+
+
 # --------------------------------------------------------------------------------------------- misc
 def msa_embed(msa, aa_idx, emb, pe, qenc):
     B, N, L_ = msa.shape

@@ -78,6 +78,12 @@ def main():
     ap.add_argument("--N", type=int, default=128)
     ap.add_argument("--L", type=int, default=256)
     ap.add_argument("--variants", default="fp16,bf16,fp16+head32,bf16+head32,fp32+head16,fp32+ln16white,fp32+ln16centred")
+    ap.add_argument("--ln-sites", default="", choices=["", "fp16", "bf16"],
+                    help="sweep: round the outputs of one group of LayerNorm sites at a time (exact-fp32 mode otherwise)")
+    ap.add_argument("--module-sweep", default="", choices=["", "fp16", "bf16"],
+                    help="sweep: one module class of every block in the 16-bit type at a time (exact-fp32 mode otherwise)")
+    ap.add_argument("--pum-sweep", default="", choices=["", "fp16", "bf16"],
+                    help="sweep: one 16-bit intermediate of PairUpdateWithMsa at a time (exact-fp32 mode otherwise)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = dict(d_input=21, d_msa=384, d_pair=288, d_node=32, d_edge=32, d_state=32, n_two_track_blocks=args.n_two,
@@ -107,14 +113,33 @@ def main():
     # the two numbers bound what operand conditioning of the LayerNorm outputs alone could buy in the body.
     from rosettafold_pytorch_amd import structure as S
 
+    blocks_all = list(model.two_track_blocks) + list(model.three_track_blocks) + [model.final_block]
+    site_sets = {
+        "projmsa": {id(b.pair_update_with_msa.proj_msa[0]) for b in blocks_all},
+        "proj2": {id(b.pair_update_with_msa.proj_msa[2]) for b in blocks_all},
+        "msa2value": {id(l.msa2value[0]) for b in blocks_all for l in b.msa_update_with_pair.encoder_layers},
+        "msaenc": {id(m_) for b in blocks_all for lay in list(b.msa_update_using_self_att.residue_wise_encoder_layers)
+                   + list(b.msa_update_using_self_att.sequence_wise_encoder_layers) for m_ in (lay.ln, lay.ff.fn[0])},
+    }
+    exact_sites = set()
+    only_sites = None      # when a set: round ONLY at these modules (the --ln-sites sweep)
+    import re
+    ln_groups = {}
+    for mname, mod in model.named_modules():
+        if type(mod).__name__ == "LayerNorm":
+            ln_groups.setdefault(re.sub(r"\.\d+\.", ".*.", re.sub(r"^(two|three)_track_blocks\.\d+\.|^final_block\.", "block.", mname)), set()).add(id(mod))
+
     @contextlib.contextmanager
     def ln_rounding(kind, dt=torch.float16):
         orig = M.ln
 
         def patched(mod, x, out_dtype=None, **kw):
             y = orig(mod, x, out_dtype=out_dtype, **kw)
+            if id(mod) in exact_sites or (only_sites is not None and id(mod) not in only_sites):
+                return y
             if out_dtype is None and y.dtype == torch.float32 and y.dim() == 4:
-                if kind == "white":
+                centre = kind == "centred" or (kind == "centred-pair" and y.shape[-1] == cfg["d_pair"] and y.shape[1] == y.shape[2])
+                if not centre:
                     y.copy_(y.to(dt).float())
                 else:
                     mu = y.mean(dim=(1, 2), keepdim=True)
@@ -139,9 +164,137 @@ def main():
         "fp16+struct32": ("fp16", [(struct, "fp32")]),
         "fp16+coordmsa32": ("fp16", [(coordmsa, "fp32")]),
     }
+    if args.ln_sites:
+        # one forward per group of LayerNorm call sites: fp16 (or bf16) rounding of THAT group's outputs alone, every other value exact
+        dt = torch.bfloat16 if args.ln_sites == "bf16" else torch.float16
+        sweep = {}
+        for gname, ids in sorted(ln_groups.items()):
+            only_sites = ids
+            with ln_rounding("white", dt):
+                out, _ = fwd("fp32")
+            m = metrics(out, ref)
+            sweep[gname] = {"modules": len(ids), "dist_rel_l2": m["rel_l2"]["dist"], "xyz_rel_l2": m["rel_l2"]["xyz"], "dist_argmax": m["dist_argmax"]}
+            print(f"[sites] {gname:70s} n={len(ids):3d} dist {m['rel_l2']['dist']:.3e} argmax {m['dist_argmax']:.4f} xyz {m['rel_l2']['xyz']:.3e}",
+                  file=sys.stderr, flush=True)
+        only_sites = None
+        res["ln_site_sweep_" + args.ln_sites] = sweep
+    if args.module_sweep:
+        # one forward per module class: THAT class of every block in the 16-bit type, everything else exact
+        groups = {}
+        for b in blocks_all:
+            for cname, child in b.named_children():
+                if hasattr(child, "run") or hasattr(child, "run3"):
+                    groups.setdefault("block." + cname, []).append(child)
+        groups["initial_coord_generation_with_msa_and_pair"] = [model.initial_coord_generation_with_msa_and_pair]
+        groups["prediction_head"] = [model.prediction_head]
+        sweep = {}
+        for gname, mods in groups.items():
+            fwd("fp32", [(mods, args.module_sweep)])
+            out, _ = fwd("fp32", [(mods, args.module_sweep)])
+            m = metrics(out, ref)
+            sweep[gname] = {"modules": len(mods), "dist_rel_l2": m["rel_l2"]["dist"], "xyz_rel_l2": m["rel_l2"]["xyz"], "dist_argmax": m["dist_argmax"]}
+            print(f"[modules] {gname:60s} n={len(mods):3d} dist {m['rel_l2']['dist']:.3e} argmax {m['dist_argmax']:.4f} xyz {m['rel_l2']['xyz']:.3e}",
+                  file=sys.stderr, flush=True)
+        res["module_sweep_" + args.module_sweep] = sweep
+    if args.pum_sweep:
+        # PairUpdateWithMsa (rf.py:430-498) alone carries the 16-bit modes' logits gap (--module-sweep): which of ITS 16-bit
+        # intermediates?  Exact-fp32 mode, one intermediate of the 13 modules rounded at a time ("-c": after removing the
+        # per-(sample, channel) mean over the picture, what an exact bias-folded centring would leave).
+        dt = DT[args.pum_sweep]
+        pums = [b.pair_update_with_msa for b in blocks_all]
+        Dp, P = cfg["d_pair"], pums[0].d_proj
+        cols = {"coevol": (0, Dp), "1d": (Dp, Dp + 4 * P), "pair": (Dp + 4 * P, 2 * Dp + 4 * P), "att": (2 * Dp + 4 * P, pums[0].d_feat)}
+        state = {"site": None, "inside": False, "in_calls": 0}
+
+        def rnd(t, centred=False):
+            if centred:
+                mu = t.mean(dim=tuple(range(1, t.dim() - 1)), keepdim=True)
+                return (t - mu).to(dt).float() + mu
+            return t.to(dt).float()
+
+        o_linear, o_cast, o_conv, o_inst = ops.linear, ops.cast, M.conv3x3, ops.instnorm
+
+        def w_linear(x, w, *a, **k):
+            site = state["site"]
+            if state["inside"] and site.startswith("feat:") and x.dim() == 4 and x.shape[-1] >= pums[0].d_feat and x.shape[-1] - pums[0].d_feat < 8:
+                key = site[5:]
+                c0, c1 = cols[key[:-2] if key.endswith("-c") else key]
+                x[..., c0:c1] = rnd(x[..., c0:c1], key.endswith("-c"))
+            return o_linear(x, w, *a, **k)
+
+        def w_cast(x, dtype):
+            r = o_cast(x, dtype)
+            if state["inside"] and state["site"] in ("x_cast", "x_cast-c"):
+                return rnd(r, state["site"].endswith("-c")).contiguous()
+            return r
+
+        def w_conv(mod, key, conv, x, dil, out_dtype=None):
+            r = o_conv(mod, key, conv, x, dil, out_dtype)
+            if state["inside"] and state["site"] in ("conv_" + key, "conv_" + key + "-c"):
+                r.copy_(rnd(r, state["site"].endswith("-c")))
+            return r
+
+        def w_inst(x, *a, **k):
+            r = o_inst(x, *a, **k)
+            if state["inside"] and k.get("residual") is None and state["site"] == "instnorm1":
+                r[0].copy_(rnd(r[0]))
+            return r
+
+        saved = []
+        for m_ in pums:
+            def run(msa_, pair_, att_, _fn=m_.run):
+                state["inside"] = True
+                try:
+                    return _fn(msa_, pair_, att_)
+                finally:
+                    state["inside"] = False
+
+            def operands(msa_, _fn=m_._msa_operands):
+                msa1d, xt, yt, Np = _fn(msa_)
+                site = state["site"]
+                if site in ("msa1d", "msa1d-c"):
+                    msa1d = rnd(msa1d, site.endswith("-c"))
+                if site == "outer_operands":
+                    xt, yt = rnd(xt), rnd(yt)
+                return msa1d, xt, yt, Np
+            object.__setattr__(m_, "run", run)
+            object.__setattr__(m_, "_msa_operands", operands)
+            saved.append(m_)
+        ops.linear, ops.cast, M.conv3x3, ops.instnorm = w_linear, w_cast, w_conv, w_inst
+        sweep = {}
+        try:
+            for site in ("feat:coevol", "feat:1d", "feat:1d-c", "feat:pair", "feat:pair-c", "feat:att", "feat:att-c", "msa1d", "msa1d-c",
+                         "outer_operands", "x_cast", "x_cast-c", "conv_c1", "conv_c1-c", "instnorm1", "conv_c2", "weights"):
+                state["site"] = site
+                if site == "weights":
+                    keep_w = [(p_, p_.data.clone()) for m_ in pums for p_ in m_.parameters()]
+                    for p_, _ in keep_w:
+                        p_.data.copy_(p_.data.to(dt).float())
+                    M.invalidate_weight_caches(model)
+                out, _ = fwd("fp32")
+                if site == "weights":
+                    for p_, d_ in keep_w:
+                        p_.data.copy_(d_)
+                    M.invalidate_weight_caches(model)
+                m = metrics(out, ref)
+                sweep[site] = {"dist_rel_l2": m["rel_l2"]["dist"], "xyz_rel_l2": m["rel_l2"]["xyz"], "dist_argmax": m["dist_argmax"]}
+                print(f"[pum] {site:20s} dist {m['rel_l2']['dist']:.3e} argmax {m['dist_argmax']:.4f} xyz {m['rel_l2']['xyz']:.3e}", file=sys.stderr, flush=True)
+        finally:
+            ops.linear, ops.cast, M.conv3x3, ops.instnorm = o_linear, o_cast, o_conv, o_inst
+            for m_ in saved:
+                object.__delattr__(m_, "run")
+                object.__delattr__(m_, "_msa_operands")
+        res["pair_update_with_msa_sweep_" + args.pum_sweep] = sweep
     for name in [v for v in args.variants.split(",") if v]:
-        if name.startswith("fp32+ln"):   # fp32+ln16white | fp32+ln16centred | fp32+lnbf16white | fp32+lnbf16centred
-            kind = "white" if name.endswith("white") else "centred"
+        if name.startswith("fp32+ln"):   # fp32+ln16white | fp32+ln16centred | fp32+lnbf16white | ... | fp32+ln16white-exact:projmsa
+            exact_sites.clear()
+            if "-exact:" in name:
+                for key in name.split("-exact:")[1].split("+"):
+                    exact_sites.update(site_sets[key])
+                name_kind = name.split("-exact:")[0]
+            else:
+                name_kind = name
+            kind = "white" if name_kind.endswith("white") else ("centred-pair" if name_kind.endswith("centredpair") else "centred")
             with ln_rounding(kind, torch.bfloat16 if "bf16" in name else torch.float16):
                 out, ms = fwd("fp32")
             res[name] = {**metrics(out, ref), "ms_eager": ms}
