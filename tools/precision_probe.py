@@ -84,6 +84,8 @@ def main():
                     help="sweep: one module class of every block in the 16-bit type at a time (exact-fp32 mode otherwise)")
     ap.add_argument("--pum-sweep", default="", choices=["", "fp16", "bf16"],
                     help="sweep: one 16-bit intermediate of PairUpdateWithMsa at a time (exact-fp32 mode otherwise)")
+    ap.add_argument("--gemm-sweep", default="", help="<block child>:<fp16|bf16>, e.g. msa_update_using_self_att:fp16 -- round the "
+                    "activation operands of that module's GEMMs one call site at a time (exact-fp32 mode otherwise)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = dict(d_input=21, d_msa=384, d_pair=288, d_node=32, d_edge=32, d_state=32, n_two_track_blocks=args.n_two,
@@ -285,6 +287,76 @@ def main():
                 object.__delattr__(m_, "run")
                 object.__delattr__(m_, "_msa_operands")
         res["pair_update_with_msa_sweep_" + args.pum_sweep] = sweep
+    if args.gemm_sweep:
+        # Inside one module class of every block (exact-fp32 mode): the activation operands of its GEMMs rounded to the 16-bit type
+        # IN PLACE, one call site at a time (what the 16-bit mode stores there; weights are left alone).  Sites = source lines of
+        # the calls.  Only for modules whose operands are private tensors (not the fp32 residual streams).
+        child, dts = args.gemm_sweep.split(":")
+        dt = DT[dts]
+        targets = [getattr(b, child) for b in blocks_all if hasattr(b, child)]
+        weights = set()
+        state = {"inside": False, "site": None, "seen": {}}
+        o_gemm = ops.gemm
+
+        def collect_weights():
+            weights.clear()
+            for m_ in model.modules():
+                c_ = getattr(m_, "_rfc", None)
+                if isinstance(c_, dict):
+                    for v in c_.values():
+                        for t_ in (v if isinstance(v, (tuple, list)) else (v,)):
+                            if torch.is_tensor(t_):
+                                weights.add(t_.data_ptr())
+
+        def w_gemm(A, B_, Cout, M_, N_, K_, **k):
+            if state["inside"]:
+                f = sys._getframe(1)
+                while f.f_code.co_filename.endswith("ops.py"):
+                    f = f.f_back
+                for tag, t_ in (("A", A), ("B", B_)):
+                    if t_.data_ptr() in weights or (t_._base is not None and t_._base.data_ptr() in weights):
+                        continue
+                    label = f"{f.f_code.co_name}:{f.f_lineno}:{tag}"
+                    state["seen"][label] = state["seen"].get(label, 0) + 1
+                    if state["site"] in (label, "ALL"):
+                        t_.copy_(t_.to(dt).float())
+            return o_gemm(A, B_, Cout, M_, N_, K_, **k)
+
+        saved = []
+        for m_ in targets:
+            for meth in ("run", "run3"):
+                fn = getattr(m_, meth, None)
+                if fn is None:
+                    continue
+
+                def wrapped(*a, _fn=fn, **k):
+                    state["inside"] = True
+                    try:
+                        return _fn(*a, **k)
+                    finally:
+                        state["inside"] = False
+                object.__setattr__(m_, meth, wrapped)
+                saved.append((m_, meth))
+        ops.gemm = w_gemm
+        sweep = {}
+        try:
+            fwd("fp32")
+            collect_weights()
+            state["seen"].clear()
+            fwd("fp32")   # dry pass: the call sites
+            sites = sorted(state["seen"])
+            print("[gemm] sites: " + ", ".join(f"{k} x{v}" for k, v in sorted(state["seen"].items())), file=sys.stderr, flush=True)
+            for site in ["ALL"] + sites:
+                state["site"] = site
+                out, _ = fwd("fp32")
+                m = metrics(out, ref)
+                sweep[site] = {"dist_rel_l2": m["rel_l2"]["dist"], "xyz_rel_l2": m["rel_l2"]["xyz"], "dist_argmax": m["dist_argmax"]}
+                print(f"[gemm] {site:40s} dist {m['rel_l2']['dist']:.3e} argmax {m['dist_argmax']:.4f} xyz {m['rel_l2']['xyz']:.3e}", file=sys.stderr, flush=True)
+        finally:
+            ops.gemm = o_gemm
+            for m_, meth in saved:
+                object.__delattr__(m_, meth)
+        res["gemm_operand_sweep_" + args.gemm_sweep] = sweep
     for name in [v for v in args.variants.split(",") if v]:
         if name.startswith("fp32+ln"):   # fp32+ln16white | fp32+ln16centred | fp32+lnbf16white | ... | fp32+ln16white-exact:projmsa
             exact_sites.clear()
