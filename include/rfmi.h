@@ -262,6 +262,10 @@ int rf_instnorm_apply(const void* x, int x_dtype, const void* sums, const float*
  *   W (x - m) + (b + W m) == W x + b;   conv3x3(x - m) + [taps outside the picture] == conv3x3(x) - const (InstanceNorm drops it).
  * mean[b,c] = sums[b,c,0] / HW from the sums of rf_instnorm_stats (fp32 [B,C]). */
 int rf_instnorm_mean(const void* sums, float* mean, int B, int64_t HW, int C, void* stream);
+/* the same mean straight from fp32 NHWC x (C % 4 == 0, 16-byte aligned): vectorised, no atomics; workspace of
+ * rf_channel_mean_ws_bytes bytes (MANDATORY: per-block partial sums, added in a fixed order). */
+int64_t rf_channel_mean_ws_bytes(int B, int64_t HW, int C);
+int rf_channel_mean(const float* x, float* mean, int B, int64_t HW, int C, void* workspace, int64_t ws_bytes, void* stream);
 /* y[b,p,c] = x[b,p,c] - mean[b,c]; x fp32 [B,HW,C], y fp32 or the 16-bit type (may alias x when fp32); C % 4 == 0, 16-byte
  * aligned pointers. */
 int rf_center_apply(const float* x, const float* mean, void* y, int y_dtype, int B, int64_t HW, int C, void* stream);

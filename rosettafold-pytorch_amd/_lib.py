@@ -63,6 +63,8 @@ PROTOTYPES = {
     "rf_instnorm_stats": [vp, i32, vp, i32, i64, i32, vp, i64, vp],
     "rf_instnorm_apply": [vp, i32, vp, vp, vp, f32, vp, i32, vp, i32, vp, i32, i32, i64, i32, vp],
     "rf_instnorm_mean": [vp, vp, i32, i64, i32, vp],
+    "rf_channel_mean_ws_bytes": [i32, i64, i32],  # returns int64
+    "rf_channel_mean": [vp, vp, i32, i64, i32, vp, i64, vp],
     "rf_center_apply": [vp, vp, vp, i32, i32, i64, i32, vp],
     "rf_center_rows": [vp, vp, i32, i32, i32, vp],
     "rf_fold_mean": [vp, i64, i32, i32, i32, i64, i32, vp, vp, vp, i32, i32, vp],
@@ -115,6 +117,7 @@ def _load(path):
         _fn.argtypes = _args
         _fn.restype = C.c_int
     handle.rf_instnorm_ws_bytes.restype = C.c_int64
+    handle.rf_channel_mean_ws_bytes.restype = C.c_int64
     handle.rf_build_info.restype = C.c_char_p
     handle.rf_build_info.argtypes = []
     return handle

@@ -32,6 +32,82 @@ extern "C" int rf_instnorm_mean(const void* sums, float* mean, int B, int64_t HW
   return rf_launch_status();
 }
 
+// ---- mean[b, c] over the HW pixels of fp32 NHWC x, C % 4 == 0: 16-byte loads, four pixels in flight per thread ---------------
+// (rf_instnorm_stats takes fp32 input through its scalar kernel: 4x slower than this at [65536, 288].)  Per-block partial sums
+// in fp32, added in block order in fp64 by the second kernel: no atomics, run-to-run identical.
+#define CM_PIX_MIN 64  // fewest pixels per block (the workspace is sized for it)
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float4* __restrict__ x, float* __restrict__ partials, int64_t HW,
+                                                          int C4, int pix) {
+  extern __shared__ float sm[];  // [ppi][C]
+  const int b = blockIdx.y;
+  const int ppi = 256 / C4;
+  const int64_t p0 = (int64_t)blockIdx.x * pix;
+  const int64_t p1 = p0 + pix < HW ? p0 + pix : HW;
+  const int ch = threadIdx.x % C4, po = threadIdx.x / C4;
+  if (po < ppi) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* xb = x + (int64_t)b * HW * C4 + ch;
+    for (int64_t p = p0 + po; p < p1; p += 8 * ppi) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t pp = p + (int64_t)u * ppi;
+        v[u] = pp < p1 ? xb[pp * C4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    ((float4*)sm)[po * C4 + ch] = s;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 4 * C4; c += 256) {
+    float t = 0.f;
+    for (int g = 0; g < ppi; ++g) t += sm[g * 4 * C4 + c];
+    partials[((int64_t)b * gridDim.x + blockIdx.x) * 4 * C4 + c] = t;
+  }
+}
+
+// 32 columns x 32 partial-sum groups per block: group g adds blocks g, g + 32, ... in order (fp64), the 32 group sums are added in
+// order by the group-0 thread: a fixed summation tree
+__global__ __launch_bounds__(1024) void channel_mean_finalize_kernel(const float* __restrict__ partials, float* __restrict__ mean,
+                                                                     int nblk, int C, double inv) {
+  __shared__ double part[32][33];
+  const int b = blockIdx.y;
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double t = 0.0;
+  if (c < C)
+    for (int k = g; k < nblk; k += 32) t += (double)partials[((int64_t)b * nblk + k) * C + c];
+  part[g][cl] = t;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    double a = part[0][cl];
+#pragma unroll
+    for (int k = 1; k < 32; ++k) a += part[k][cl];
+    mean[(int64_t)b * C + c] = (float)(a * inv);
+  }
+}
+
+extern "C" int64_t rf_channel_mean_ws_bytes(int B, int64_t HW, int C) {
+  return (int64_t)B * cdiv(HW, CM_PIX_MIN) * C * (int64_t)sizeof(float);
+}
+
+extern "C" int rf_channel_mean(const float* x, float* mean, int B, int64_t HW, int C, void* workspace, int64_t ws_bytes,
+                               void* stream) {
+  if (!x || !mean || B <= 0 || HW <= 0 || C <= 0 || C % 4 != 0 || C / 4 > 256 || ((uintptr_t)x % 16)) return RF_EINVAL;
+  if (!workspace || ws_bytes < rf_channel_mean_ws_bytes(B, HW, C)) return RF_EINVAL;
+  // pixels per block: ~2048 blocks per launch (8 per CU), between CM_PIX_MIN and 512
+  int64_t pix = (HW * B + 2047) / 2048;
+  pix = pix < CM_PIX_MIN ? CM_PIX_MIN : (pix > 512 ? 512 : pix);
+  const unsigned nblk = cdiv(HW, pix);
+  const int C4 = C / 4, ppi = 256 / C4;
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(nblk, B), dim3(256), (size_t)ppi * C * sizeof(float), (hipStream_t)stream,
+                     (const float4*)x, (float*)workspace, HW, C4, (int)pix);
+  hipLaunchKernelGGL(channel_mean_finalize_kernel, dim3(cdiv(C, 32), B), dim3(1024), 0, (hipStream_t)stream,
+                     (const float*)workspace, mean, (int)nblk, C, 1.0 / (double)HW);
+  return rf_launch_status();
+}
+
 // ---- y[b, p, c] = x[b, p, c] - mean[b, c]   (x fp32 NHWC, y fp32 or the 16-bit type; C % 4 == 0) ---------------------------
 // The grid stride is a multiple of the C / 4 chunks of a pixel, so a thread keeps ONE channel chunk: its four means live in
 // registers and the loop is a 16-byte load, four subtractions and one 8- or 16-byte store.
@@ -45,18 +121,22 @@ __global__ __launch_bounds__(256) void center_apply_kernel(const float4* __restr
   const int c4 = (int)(e % C4);
   const float4 m = ((const float4*)(mean + (int64_t)b * C4 * 4))[c4];
   const float4* xb = x + (int64_t)b * chunks;
-  for (; e < chunks; e += stride) {
-    float4 v = xb[e];
+  auto put = [&](int64_t i, float4 v) {
     v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w;
     if (H16OUT) {
       uint2 o;
       o.x = rf_pack2_h16(v.x, v.y);
       o.y = rf_pack2_h16(v.z, v.w);
-      ((uint2*)y)[(int64_t)b * chunks + e] = o;
+      ((uint2*)y)[(int64_t)b * chunks + i] = o;
     } else {
-      ((float4*)y)[(int64_t)b * chunks + e] = v;
+      ((float4*)y)[(int64_t)b * chunks + i] = v;
     }
+  };
+  for (; e + 3 * stride < chunks; e += 4 * stride) {   // four 16-byte loads in flight per thread
+    const float4 v0 = xb[e], v1 = xb[e + stride], v2 = xb[e + 2 * stride], v3 = xb[e + 3 * stride];
+    put(e, v0); put(e + stride, v1); put(e + 2 * stride, v2); put(e + 3 * stride, v3);
   }
+  for (; e < chunks; e += stride) put(e, xb[e]);
 }
 
 extern "C" int rf_center_apply(const float* x, const float* mean, void* y, int y_dtype, int B, int64_t HW, int C,
@@ -66,7 +146,7 @@ extern "C" int rf_center_apply(const float* x, const float* mean, void* y, int y
   if (((uintptr_t)x % 16) || ((uintptr_t)mean % 16) || ((uintptr_t)y % 16)) return RF_EINVAL;
   const int C4 = C / 4;
   const int64_t chunks = HW * C4;
-  unsigned gx = min(cdiv(chunks, 256), 2048u);
+  unsigned gx = min(cdiv(chunks, 4 * 256), 2048u);
   {  // grid stride (gx * 256) a multiple of C4
     unsigned g = (unsigned)C4, r = 256u % (unsigned)C4;
     while (r) { const unsigned t = g % r; g = r; r = t; }   // gcd(C4, 256)
@@ -81,35 +161,35 @@ extern "C" int rf_center_apply(const float* x, const float* mean, void* y, int y
 }
 
 // ---- small tensors: mean over the R rows of x[b] (fp32 [B, R, C]) and x -= mean in place ----------------------------------
-// One block per sample; thread t owns channel t % C of the rows t / C, t / C + 256 / C, ... (C divides 256) or channels
-// t, t + 256, ... of every row (any other C); fixed summation order, no atomics.
+// One block per (sample, slab of 8 channels): 32 row groups x 8 channels, the groups' sums added in order by the first 8
+// threads (fixed summation order, no atomics); C % 8 != 0: one block per sample, a thread per channel.
 __global__ __launch_bounds__(256) void center_rows_kernel(float* __restrict__ x, float* __restrict__ mean, int R, int C) {
   __shared__ float part[256];
-  __shared__ float mu[256];
-  float* xb = x + (int64_t)blockIdx.x * R * C;
+  __shared__ float mu[8];
+  float* xb = x + (int64_t)blockIdx.y * R * C;
   const int t = threadIdx.x;
-  if (C <= 256 && 256 % C == 0) {
-    const int c = t % C, g = t / C, G = 256 / C;
+  if (C % 8 == 0) {
+    const int c = blockIdx.x * 8 + (t & 7), g = t >> 3;
     float s = 0.f;
-    for (int r = g; r < R; r += G) s += xb[(int64_t)r * C + c];
+    for (int r = g; r < R; r += 32) s += xb[(int64_t)r * C + c];
     part[t] = s;
     __syncthreads();
-    if (t < C) {
+    if (t < 8) {
       float a = 0.f;
-      for (int k = 0; k < G; ++k) a += part[k * C + t];
+      for (int k = 0; k < 32; ++k) a += part[k * 8 + t];
       a /= (float)R;
       mu[t] = a;
-      mean[(int64_t)blockIdx.x * C + t] = a;
+      mean[(int64_t)blockIdx.y * C + c] = a;
     }
     __syncthreads();
-    const float m = mu[c];
-    for (int r = g; r < R; r += G) xb[(int64_t)r * C + c] -= m;
+    const float m = mu[t & 7];
+    for (int r = g; r < R; r += 32) xb[(int64_t)r * C + c] -= m;
   } else {
     for (int c = t; c < C; c += 256) {
       float s = 0.f;
       for (int r = 0; r < R; ++r) s += xb[(int64_t)r * C + c];
       s /= (float)R;
-      mean[(int64_t)blockIdx.x * C + c] = s;
+      mean[(int64_t)blockIdx.y * C + c] = s;
       for (int r = 0; r < R; ++r) xb[(int64_t)r * C + c] -= s;
     }
   }
@@ -117,7 +197,7 @@ __global__ __launch_bounds__(256) void center_rows_kernel(float* __restrict__ x,
 
 extern "C" int rf_center_rows(float* x, float* mean, int B, int R, int C, void* stream) {
   if (!x || !mean || B <= 0 || R <= 0 || C <= 0) return RF_EINVAL;
-  hipLaunchKernelGGL(center_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, mean, R, C);
+  hipLaunchKernelGGL(center_rows_kernel, dim3(C % 8 == 0 ? C / 8 : 1, B), dim3(256), 0, (hipStream_t)stream, x, mean, R, C);
   return rf_launch_status();
 }
 

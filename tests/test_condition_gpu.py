@@ -45,12 +45,15 @@ def test_center_rows(B, R_, C):
 
 
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,H,W,C", [(1, 64, 64, 288), (2, 17, 23, 128), (1, 5, 7, 4), (2, 32, 32, 36)])
+@pytest.mark.parametrize("B,H,W,C", [(1, 64, 64, 288), (2, 17, 23, 128), (1, 5, 7, 4), (2, 32, 32, 36), (1, 40, 33, 1024)])
 def test_channel_mean_and_center_apply(B, H, W, C, out_dtype):
     x = rn(B, H, W, C) + 3.0 * rn(1, 1, 1, C, seed=1)
     mean = ops.channel_mean(x)
     ref = x.double().mean((1, 2))
     assert torch.allclose(mean.double(), ref, atol=1e-5)
+    # the vectorised fp32 kernel (rf_channel_mean) and the InstanceNorm statistics path (rf_instnorm_stats + rf_instnorm_mean, the
+    # one a row-sharded picture takes) give the same means
+    assert torch.allclose(ops.center_channels(x.clone()), x - mean[:, None, None, :], atol=1e-5)
     want = (x - mean[:, None, None, :]).to(out_dtype)
     y = ops.center_apply(x, mean, out_dtype=out_dtype)
     assert y.dtype == out_dtype and torch.equal(y, want)
