@@ -266,6 +266,9 @@ int rf_instnorm_mean(const void* sums, float* mean, int B, int64_t HW, int C, vo
  * rf_channel_mean_ws_bytes bytes (MANDATORY: per-block partial sums, added in a fixed order). */
 int64_t rf_channel_mean_ws_bytes(int B, int64_t HW, int C);
 int rf_channel_mean(const float* x, float* mean, int B, int64_t HW, int C, void* workspace, int64_t ws_bytes, void* stream);
+/* an ESTIMATE of that mean from nsample evenly spaced rows of x [B,R,C] (fp32 or 16-bit): the identities hold for any constant,
+ * the attention layers condition their value operand with it (model.py: _value_conditioning). */
+int rf_sample_mean(const void* x, int x_dtype, float* mean, int B, int64_t R, int C, int nsample, void* stream);
 /* y[b,p,c] = x[b,p,c] - mean[b,c]; x fp32 [B,HW,C], y fp32 or the 16-bit type (may alias x when fp32); C % 4 == 0, 16-byte
  * aligned pointers. */
 int rf_center_apply(const float* x, const float* mean, void* y, int y_dtype, int B, int64_t HW, int C, void* stream);

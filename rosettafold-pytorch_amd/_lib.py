@@ -65,6 +65,7 @@ PROTOTYPES = {
     "rf_instnorm_mean": [vp, vp, i32, i64, i32, vp],
     "rf_channel_mean_ws_bytes": [i32, i64, i32],  # returns int64
     "rf_channel_mean": [vp, vp, i32, i64, i32, vp, i64, vp],
+    "rf_sample_mean": [vp, i32, vp, i32, i64, i32, i32, vp],
     "rf_center_apply": [vp, vp, vp, i32, i32, i64, i32, vp],
     "rf_center_rows": [vp, vp, i32, i32, i32, vp],
     "rf_fold_mean": [vp, i64, i32, i32, i32, i64, i32, vp, vp, vp, i32, i32, vp],

@@ -201,6 +201,35 @@ extern "C" int rf_center_rows(float* x, float* mean, int B, int R, int C, void* 
   return rf_launch_status();
 }
 
+// ---- an ESTIMATE of the per-channel mean of a large [B, R, C] tensor from nsample evenly spaced rows -----------------------
+// (the identities above hold for ANY constant: the closer to the true mean, the better the conditioning -- 2048 of 32768 rows
+// leave 1/45 of the spread.)  One block per (sample, slab of 8 channels): 32 row groups x 8 channels, fixed summation order.
+__global__ __launch_bounds__(256) void sample_mean_kernel(const void* __restrict__ x, int dt, float* __restrict__ mean, int64_t R,
+                                                          int C, int nsample) {
+  __shared__ float part[256];
+  const int t = threadIdx.x;
+  const int c = blockIdx.x * 8 + (t & 7), g = t >> 3;
+  const int64_t base = (int64_t)blockIdx.y * R * C;
+  float s = 0.f;
+  if (c < C)
+    for (int k = g; k < nsample; k += 32) s += ld(x, dt, base + ((int64_t)k * R / nsample) * C + c);
+  part[t] = s;
+  __syncthreads();
+  if (t < 8 && c < C) {
+    float a = 0.f;
+    for (int k = 0; k < 32; ++k) a += part[k * 8 + t];
+    mean[(int64_t)blockIdx.y * C + c] = a / (float)nsample;
+  }
+}
+
+extern "C" int rf_sample_mean(const void* x, int x_dtype, float* mean, int B, int64_t R, int C, int nsample, void* stream) {
+  RF_CHECK_DT(x_dtype);
+  if (!x || !mean || B <= 0 || R <= 0 || C <= 0 || nsample <= 0) return RF_EINVAL;
+  if (nsample > R) nsample = (int)R;
+  hipLaunchKernelGGL(sample_mean_kernel, dim3(cdiv(C, 8), B), dim3(256), 0, (hipStream_t)stream, x, x_dtype, mean, R, C, nsample);
+  return rf_launch_status();
+}
+
 // ---- the constant's way through a weight matrix --------------------------------------------------------------------------
 // sum_seg != 0:  out[b, n]    = (bias ? bias[n] : 0) + sum_{s < nseg} sum_{k < K} w[n, k0 + s * seg_stride + k] * mean[b, k]
 // sum_seg == 0:  out[b, s, n] = (bias ? bias[n] : 0) +                 sum_{k < K} w[n, k0 + s * seg_stride + k] * mean[b, k]

@@ -205,6 +205,33 @@ class RFModule(nn.Module):
             self._rfc[k] = v
         return v
 
+    # operand conditioning of an attention layer's value path (16-bit modes; csrc/condition.hip) -----------------------------------
+    def value_conditioning(self, xn, to_v, to_out, lead=()):
+        """The attention output o = sum_j a_ij v_j (a_i. sums to one: softmax rows, or FAVOR's ratio) is a per-sample constant
+        c ~ mean_j v_j plus a part 10-30x smaller at random init, and it is the 16-bit operand of the output projection:
+        rounded with the constant it was 4e-2 of the bf16 mode's 5e-2 logits gap (tools/precision_probe.py --gemm-sweep
+        msa_update_using_self_att:bf16; the linear attention's context, rounded for its second GEMM, another 2e-2).  With
+        mu = an estimate of mean(xn) (rf_sample_mean) and c = W_v mu + b_v:
+            v - c = W_v xn - W_v mu            the value block of the projection gets the bias -W_v mu instead of b_v,
+            o - c = sum_j a_ij (v_j - c)       the attention kernels run unchanged on the centred values,
+            W_o (o - c) + (b_o + W_o c)        the output projection gets the bias b_o + W_o b_v + (W_o W_v) mu.
+        Returns (fp32 [B, n_lead + d_v] bias of the projection whose output columns are [lead..., v], fp32 [B, d_out] output bias);
+        `lead`: the Linear modules in front of v in a fused projection (their biases pass through)."""
+        def make():
+            wv, wo = to_v.weight.detach().float(), to_out.weight.detach().float()
+            dev = wv.device
+            bl = [(_f(m_.bias) if m_.bias is not None else torch.zeros(m_.weight.shape[0], device=dev)) for m_ in lead]
+            bo = _f(to_out.bias) if to_out.bias is not None else torch.zeros(wo.shape[0], device=dev)
+            if to_v.bias is not None:
+                bo = bo + wo @ _f(to_v.bias)
+            nl = sum(m_.weight.shape[0] for m_ in lead)
+            wc = torch.cat([torch.zeros(nl, wv.shape[1], device=dev), -wv, wo @ wv]).contiguous()
+            bc = torch.cat(bl + [torch.zeros(wv.shape[0], device=dev), bo]).contiguous()
+            return wc, bc, nl + wv.shape[0]
+        wc, bc, npre = self.cached(("vcond", len(lead)), make)
+        r = ops.fold_mean(wc, ops.sample_mean(xn), bc)
+        return r[:, :npre], r[:, npre:]
+
     # kernel-ready views of parameter containers -------------------------------------------------
     def wt(self, key, lin, kpad=None):
         def make():
@@ -577,6 +604,10 @@ class SoftTiedAttentionOverResidues(RFModule):
         H, dh = self.n_heads, self.d_head
         dev = xn.device
         pw = self.poswise_weight
+        if RT.condition and ops.is_h16(T()) and B > 1:
+            # the value conditioning carries a per-sample bias: one sample per projection launch
+            outs = [self.attend(xn[b:b + 1], x_res[b:b + 1], want_att, None, drops) for b in range(B)]
+            return (torch.cat([o_[0] for o_ in outs]) if want_att else None), None
         if (RT.fused_tied and RT.tied_v2 and ops.is_h16(T()) and dh == 32 and Lr in (64, 128, 192, 256) and H <= 16
                 and N % 16 == 0 and N // 16 in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16) and (B * N * Lr) % 256 == 0 and B * N * Lr >= 16384
                 and (6 if Lr >= 256 else 8) * (4096 + Lr * 64) + 1024 + N * 256 <= 160 * 1024):
@@ -606,9 +637,12 @@ class SoftTiedAttentionOverResidues(RFModule):
         else:
             ops.poswise(q0, D, qkp, 3 * D, 2 * D, dh, dh, None, qkp, 3 * D, 0, dh, B, N, Lr, H, pw.scale, self.scale)
         # v transposed: v_t[b,n,(h,d),l]
+        bv, bo = _f(self.to_v.bias), _f(self.to_out.bias)
+        if RT.condition and ops.is_h16(T()) and B == 1:
+            bv, bo = (t_[0] for t_ in self.value_conditioning(xn, self.to_v, self.to_out))
         v_t = torch.empty(B, N, D, Lr, device=dev, dtype=T())
         ops.gemm(self.wt("v", self.to_v), xn, v_t, D, Lr, D, batch=(B * N, 1, 1), b_bs=(Lr * D, 0, 0),
-                 c_bs=(D * Lr, 0, 0), c_row=(0, 0, Lr), bias=_f(self.to_v.bias), bias_mode=L.BIAS_ROW)
+                 c_bs=(D * Lr, 0, 0), c_row=(0, 0, Lr), bias=bv, bias_mode=L.BIAS_ROW)
         # logits[b,h,i,j] = sum_{n,d} q k   (contraction over N*dh, rf.py:254), softmax over j (rf.py:255)
         W3 = 3 * D
         att = torch.empty(B, H, Lr, Lr, device=dev, dtype=T())
@@ -629,7 +663,7 @@ class SoftTiedAttentionOverResidues(RFModule):
                  a_bs=(H * Lr * Lr, Lr * Lr, 0), a_row=(0, 0, Lr),
                  b_bs=(N * D * Lr, dh * Lr, 0), b_row=(dh, D * Lr, Lr),
                  c_bs=(N * Lr * D, dh, 0), c_row=(0, 0, D), c_col=(dh, Lr * D))
-        xn_next = project_into_residual(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln, drops)
+        xn_next = project_into_residual(out, self.wt("o", self.to_out), bo, x_res, next_ln, drops)
         return att_sym, xn_next
 
     def attend_head_major(self, xn, x_res, want_att, next_ln=None, drops=()):
@@ -655,7 +689,10 @@ class SoftTiedAttentionOverResidues(RFModule):
         # the scaling, and the logits kernel neither stages the weights nor rescales its fragments (round 2: 15-20 us of VALU)
         # ... when the projection runs on the kernel whose epilogue knows the row-group scale (d_msa = 288: N = 864 does not)
         fold = RT.tied_fold_w and dh % 16 == 0 and ops.gemm_takes_row_scale(B * N * Lr, 3 * D, D)
-        ops.gemm(xn, self.wcat("qkv", lins), qkv, B * N * Lr, 3 * D, D, bias=self.bcat("qkv", lins),
+        bqkv, bo = self.bcat("qkv", lins), _f(self.to_out.bias)
+        if RT.condition and B == 1:   # (attend() hands this path one sample at a time when the conditioning is on)
+            bqkv, bo = (t_[0] for t_ in self.value_conditioning(xn, self.to_v, self.to_out, lead=(self.to_q, self.to_k)))
+        ops.gemm(xn, self.wcat("qkv", lins), qkv, B * N * Lr, 3 * D, D, bias=bqkv,
                  c_row=(Lr, G * Lr * dh, dh), c_col=(dh, Lr * dh),
                  rs=(w, H * N * Lr, N * Lr, dh, D, self.scale) if fold else None)
         att = torch.empty(B, H, Lr, Lr, device=dev, dtype=T())
@@ -663,7 +700,7 @@ class SoftTiedAttentionOverResidues(RFModule):
         out = torch.empty(B, N, Lr, D, device=dev, dtype=T())
         ops.tied_attention(qkv[:, :, 0:H], qkv[:, :, H:2 * H], qkv[:, :, 2 * H:], out.view(B, N, Lr, H, dh).permute(0, 1, 3, 2, 4),
                            att, w=None if fold else w, qscale=1.0 if fold else self.scale, att_sym=att_sym)
-        xn_next = project_into_residual(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln, drops)
+        xn_next = project_into_residual(out, self.wt("o", self.to_out), bo, x_res, next_ln, drops)
         return att_sym, xn_next
 
     def attend_long_rows(self, xn, x_res, want_att, next_ln=None, drops=()):
@@ -692,15 +729,18 @@ class SoftTiedAttentionOverResidues(RFModule):
         att_sym = torch.empty(B, Lr, Lr, H, device=dev, dtype=F32) if want_att else None
         ops.tied_logits(qk[:, :, 0:H], qk[:, :, H:], att, att_sym)
         # v transposed: v_t[b,n,(h,d),l];  out[b,n,i,(h,d)] = sum_j att[b,h,i,j] v[b,n,h,j,d]   (rf.py:257-258)
+        bv, bo = _f(self.to_v.bias), _f(self.to_out.bias)
+        if RT.condition and B == 1:
+            bv, bo = (t_[0] for t_ in self.value_conditioning(xn, self.to_v, self.to_out))
         v_t = torch.empty(B, N, D, Lr, device=dev, dtype=T())
         ops.gemm(self.wt("v", self.to_v), xn, v_t, D, Lr, D, batch=(B * N, 1, 1), b_bs=(Lr * D, 0, 0),
-                 c_bs=(D * Lr, 0, 0), c_row=(0, 0, Lr), bias=_f(self.to_v.bias), bias_mode=L.BIAS_ROW)
+                 c_bs=(D * Lr, 0, 0), c_row=(0, 0, Lr), bias=bv, bias_mode=L.BIAS_ROW)
         out = torch.empty(B, N, Lr, D, device=dev, dtype=T())
         ops.gemm(att, v_t, out, Lr, N * dh, Lr, batch=(B, H, 1),
                  a_bs=(H * Lr * Lr, Lr * Lr, 0), a_row=(0, 0, Lr),
                  b_bs=(N * D * Lr, dh * Lr, 0), b_row=(dh, D * Lr, Lr),
                  c_bs=(N * Lr * D, dh, 0), c_row=(0, 0, D), c_col=(dh, Lr * D))
-        xn_next = project_into_residual(out, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln, drops)
+        xn_next = project_into_residual(out, self.wt("o", self.to_out), bo, x_res, next_ln, drops)
         return att_sym, xn_next
 
     def forward(self, x):
@@ -743,6 +783,7 @@ class PerformerSelfAttention(RFModule):
         inner = dim_head * heads
         self.heads, self.dim_head, self.inner = heads, dim_head, inner
         self.p_dropout = dropout   # (performer_pytorch.SelfAttention: nn.Dropout on the projected output)
+        self.condition_v = False   # value conditioning of the 16-bit modes (RFModule.value_conditioning): the MSA track switches it on
         self.generalized = generalized_attention
         self.fast_attention = _FastAttention(dim_head, int(dim_head * math.log(dim_head)))
         self.to_q = Linear(dim, inner, bias=False)
@@ -782,6 +823,15 @@ class PerformerSelfAttention(RFModule):
         if seq_group is not None and not gen:
             raise NotImplementedError("sequence-sharded attention is built for the generalized (ReLU) feature map of the pair "
                                       "track only: the softmax feature map needs the global key maximum first")
+        cond = RT.condition and self.condition_v and ops.is_h16(T()) and seq_group is None
+        if cond and B > 1:   # per-sample bias: one sample per launch
+            for b in range(B):
+                self.attend(xn[b:b + 1], x_res[b:b + 1], axis, None, None, drops)
+            return None
+        bqkv, bv, bo = None, None, _f(self.to_out.bias)
+        if cond:
+            bqkv, bo = (t_[0] for t_ in self.value_conditioning(xn, self.to_v, self.to_out, lead=(self.to_q, self.to_k)))
+            bv = bqkv[2 * inner:]
         if seq_group is None and RT.fused_favor and ops.is_h16(T()) and dh == 64 and m == M_FEAT and (
                 Ls in (64, 128, 256) or (gen and Ls > 256 and Ls % 256 == 0)):
             # fused path: one projection GEMM (q|k|v) + one persistent kernel; q', k', ctx never leave the chip
@@ -798,12 +848,12 @@ class PerformerSelfAttention(RFModule):
                 if axis == 2:
                     # row m = (b, p1, p2) with the sequence along p2: offset (m / L2) * so_c + (m % L2) * dh -- one launch, the
                     # register-resident-weight GEMM's split-C epilogue (csrc/gemm_wreg.hip)
-                    ops.gemm(xn, wqkv, qkv, R, W3, D, c_row=(L2, so_c, dh), c_col=(dh, Ls * dh))
+                    ops.gemm(xn, wqkv, qkv, R, W3, D, c_row=(L2, so_c, dh), c_col=(dh, Ls * dh), bias=bqkv)
                 else:
                     # sequence along p1: offset b * Lo * so_c + p2 * so_c + p1 * dh is a three-level split: one launch per
                     # batch element (row m = p1 * L2 + p2 inside it: (m / L2) * dh + (m % L2) * so_c)
                     for b in range(B):
-                        ops.gemm(xn[b], wqkv, qkv[b], RB, W3, D, c_row=(L2, dh, so_c), c_col=(dh, Ls * dh))
+                        ops.gemm(xn[b], wqkv, qkv[b], RB, W3, D, c_row=(L2, dh, so_c), c_col=(dh, Ls * dh), bias=bqkv)
                 ops.favor_attention(qkv, pcf, o, (Lo * so_c, so_c, dh, Ls * dh), (RB * inner, so * inner, ss * inner),
                                     0, H * Ls * dh, 2 * H * Ls * dh, B, Lo, H, Ls, dh, m, not gen, eps)
             else:
@@ -813,19 +863,19 @@ class PerformerSelfAttention(RFModule):
                     nb = pr // RB
                     qkv = torch.empty(pr, W3, device=dev, dtype=T())
                     xn2, xr2 = xn.view(R, D), x_res.view(R, -1)
-                    wo, bo = self.wt("o", self.to_out), _f(self.to_out.bias)
+                    wo = self.wt("o", self.to_out)
                     nxt, fused = torch.empty(R, xr2.shape[1], device=dev, dtype=T()) if next_ln is not None else None, True
                     for r0 in range(0, R, pr):
-                        ops.linear(xn2[r0:r0 + pr], wqkv, None, out=qkv)
+                        ops.linear(xn2[r0:r0 + pr], wqkv, bqkv, out=qkv)
                         op = o[r0:r0 + pr]
                         ops.favor_attention(qkv, pcf, op, (RB * W3, so * W3, ss * W3, dh), (RB * inner, so * inner, ss * inner),
                                             0, inner, 2 * inner, nb, Lo, H, Ls, dh, m, not gen, eps)
                         fused &= ops.linear_residual_ln(op, wo, bo, xr2[r0:r0 + pr], next_ln, nxt[r0:r0 + pr] if nxt is not None else None) is not None
                     return nxt.view(x_res.shape) if nxt is not None and fused else None
-                qkv = ops.linear(xn, wqkv, None)
+                qkv = ops.linear(xn, wqkv, bqkv)
                 ops.favor_attention(qkv, pcf, o, (RB * W3, so * W3, ss * W3, dh), (RB * inner, so * inner, ss * inner),
                                     0, inner, 2 * inner, B, Lo, H, Ls, dh, m, not gen, eps)
-            return project_into_residual(o, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln, drops)
+            return project_into_residual(o, self.wt("o", self.to_out), bo, x_res, next_ln, drops)
         qk = ops.linear(xn, self.wcat("qk", [self.to_q, self.to_k]), None)  # [R, 2*inner]
         # q' [B,Lo,H,Ls,M_PAD]
         dq = torch.empty(B, Lo, H, Ls, M_PAD, device=dev, dtype=T())
@@ -849,7 +899,8 @@ class PerformerSelfAttention(RFModule):
         ops.copy4d(ones_row, (0, 0, Ls, 1), vt, (0, 0, VT_ROWS * Ls, 1), (1, 1, B * Lo * H, Ls), y_off=dh * Ls)
         ops.gemm(self.wt("v", self.to_v), xn, vt, inner, Ls, D, batch=(B, Lo, 1),
                  b_bs=(RB * D, so * D, 0), b_row=(0, 0, ss * D),
-                 c_bs=(Lo * H * VT_ROWS * Ls, H * VT_ROWS * Ls, 0), c_row=(dh, VT_ROWS * Ls, Ls))
+                 c_bs=(Lo * H * VT_ROWS * Ls, H * VT_ROWS * Ls, 0), c_row=(dh, VT_ROWS * Ls, Ls),
+                 bias=bv, bias_mode=L.BIAS_ROW if bv is not None else None)
         # context^T [S,80,M_PAD] = v^T k'
         # fp16 operands (range 65504): the context is a sum over the whole sequence, so it is stored scaled by 2^-ceil(log2 Ls_total)
         # (on the fp32 accumulators, before the rounding) exactly as csrc/favor.hip does in the fused kernel; numerator and
@@ -876,7 +927,7 @@ class PerformerSelfAttention(RFModule):
                  c_bs=(RB * H * VT_ROWS, so * H * VT_ROWS, VT_ROWS), c_row=(0, 0, ss * H * VT_ROWS))
         o = torch.empty(R, inner, device=dev, dtype=T())
         ops.linattn_normalize(num, VT_ROWS, o, dh, R * H, dh)
-        return project_into_residual(o, self.wt("o", self.to_out), _f(self.to_out.bias), x_res, next_ln, drops)
+        return project_into_residual(o, self.wt("o", self.to_out), bo, x_res, next_ln, drops)
 
     def forward(self, x):
         """x [S, n, dim] -> [S, n, dim] (library call surface)."""
@@ -904,6 +955,7 @@ class EncoderLayer(RFModule):
             if return_att:
                 raise NotImplementedError("PerformerSelfAttention does not support return_att.")
             self.attn = PerformerSelfAttention(dim=d_msa, heads=n_heads, dropout=p_dropout, **performer_kws)
+            self.attn.condition_v = True
         else:
             raise NotImplementedError
         self.ln = LayerNorm(d_msa)

@@ -426,6 +426,17 @@ def channel_mean(x, row_group=None, rows_global=None):
     return mean
 
 
+def sample_mean(x, nsample=2048):
+    """fp32 [B, C] estimate of the per-channel mean of x [B, ..., C] (fp32 / 16-bit, contiguous) from nsample evenly spaced rows."""
+    B, Cc = x.shape[0], x.shape[-1]
+    _need_cuda(x)
+    if not x.is_contiguous():
+        raise ValueError("sample_mean: contiguous input")
+    mean = torch.empty(B, Cc, device=x.device, dtype=F32)
+    check(lib.rf_sample_mean(ptr(x), dcode(x.dtype), ptr(mean), B, x.numel() // (B * Cc), Cc, nsample, stream()), "rf_sample_mean")
+    return mean
+
+
 def center_apply(x, mean, out=None, out_dtype=None):
     """out[b, ..., c] = x[b, ..., c] - mean[b, c]; x fp32 [B, ..., C] contiguous, out fp32 (default: in place) or 16-bit."""
     B, Cc = x.shape[0], x.shape[-1]

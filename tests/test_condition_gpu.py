@@ -180,3 +180,71 @@ def test_prediction_head_conditioning(mode):
     cond = max(rel(v, ref[k]) for k, v in head(pair).items())
     print(f"\n[PredictionHead {mode}] plain {plain:.3e}  conditioned {cond:.3e}")
     assert cond < 0.5 * plain, (plain, cond)
+
+
+# ---- the attention layers' value path (RFModule.value_conditioning) ------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sample_mean(dtype):
+    B, R_, C = 2, 5000, 40
+    x = (rn(B, R_, C) + 4.0 * rn(1, 1, C, seed=1)).to(dtype)
+    got = ops.sample_mean(x, nsample=512)
+    rows = (torch.arange(512, device=DEV) * R_) // 512
+    want = x[:, rows].float().mean(1)
+    assert torch.allclose(got, want, atol=1e-4)
+    assert (got - x.float().mean(1)).abs().max() < 0.25          # and it is an estimate of the mean (sigma / sqrt(512) = 0.044)
+    few = ops.sample_mean(x[:, :7].contiguous(), nsample=512)     # more samples asked than rows: every row once
+    assert torch.allclose(few, x[:, :7].float().mean(1), atol=1e-4)
+
+
+def _offset_biases(m, seed, scale=0.5):
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(scale * torch.randn(p.shape, generator=torch.Generator().manual_seed(seed + p.numel())).to(DEV))
+
+
+@pytest.mark.parametrize("mode", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("kind,B,N,L", [("tied", 1, 16, 64), ("tied", 2, 16, 64), ("tied", 1, 128, 256), ("performer", 1, 64, 32),
+                                         ("performer", 2, 64, 32), ("performer", 1, 128, 64)])
+def test_encoder_layer_value_conditioning(kind, B, N, L, mode):
+    """The attention update of an MSA encoder layer (rf.py:284-354: to_out(attention(LN(x)))) on a stream with a per-sample
+    constant: the error of its position-dependent part against the exact-fp32 mode drops several-fold."""
+    torch.manual_seed(5)
+    D = 384 if (N, L) == (128, 256) else 96
+    lay = R.EncoderLayer(d_msa=D, d_ff=2 * D, n_heads=D // 32, p_dropout=0.0, tied=(kind == "tied"), performer=(kind == "performer")).to(DEV)
+    _offset_biases(lay, 11)
+    x = rn(B, N, L, D) + 6.0 * rn(B, 1, 1, D, seed=1)
+
+    def update():
+        xn = M.ln(lay.ln, x)
+        res = ops.zeros(B, N, L, D, device=DEV, dtype=torch.float32)
+        if kind == "tied":
+            lay.attn.attend(xn, res, False)
+        else:
+            lay.attn.attend(xn, res, 2)
+        return res - res.mean(dim=(1, 2), keepdim=True)   # the part of the update that varies over the positions
+    R.set_compute_dtype(torch.float32)
+    ref = update()
+    R.set_compute_dtype(mode)
+    M.RT.condition = False
+    plain = rel(update(), ref)
+    M.RT.condition = True
+    cond = rel(update(), ref)
+    print(f"\n[attention update {kind} B={B} N={N} L={L} {mode}] plain {plain:.3e}  conditioned {cond:.3e}")
+    assert cond < 0.5 * plain, (plain, cond)
+
+
+def test_value_conditioning_is_exact_algebra_in_fp32_terms():
+    """v - c, then W_o (o - c) + (b_o + W_o c): with the attention weights summing to one the result is the unconditioned one --
+    checked on the tied layer in fp16 with inputs WITHOUT a common mode (conditioning must then change nothing beyond rounding)."""
+    torch.manual_seed(6)
+    lay = R.EncoderLayer(d_msa=96, d_ff=192, n_heads=3, p_dropout=0.0, tied=True).to(DEV)
+    x = rn(1, 16, 64, 96)
+    R.set_compute_dtype(torch.float32)
+    ref = lay(x) - x
+    R.set_compute_dtype(torch.float16)
+    M.RT.condition = False
+    plain = rel(lay(x) - x, ref)
+    M.RT.condition = True
+    cond = rel(lay(x) - x, ref)
+    assert cond < 1.5 * plain + 1e-4 and plain < 1e-2, (plain, cond)

@@ -86,6 +86,7 @@ def main():
                     help="sweep: one 16-bit intermediate of PairUpdateWithMsa at a time (exact-fp32 mode otherwise)")
     ap.add_argument("--gemm-sweep", default="", help="<block child>:<fp16|bf16>, e.g. msa_update_using_self_att:fp16 -- round the "
                     "activation operands of that module's GEMMs one call site at a time (exact-fp32 mode otherwise)")
+    ap.add_argument("--gemm-sites", default="", help="with --gemm-sweep: only these sites (comma separated; suffix -c / -cn / -cl: centred rounding)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     cfg = dict(d_input=21, d_msa=384, d_pair=288, d_node=32, d_edge=32, d_state=32, n_two_track_blocks=args.n_two,
@@ -320,6 +321,15 @@ def main():
                     state["seen"][label] = state["seen"].get(label, 0) + 1
                     if state["site"] in (label, "ALL"):
                         t_.copy_(t_.to(dt).float())
+                    elif state["site"] == label + "-c":      # centred: minus the per-channel mean over ALL rows (one constant vector)
+                        mu = t_.reshape(-1, t_.shape[-1]).mean(0)
+                        t_.copy_((t_ - mu).to(dt).float() + mu)
+                    elif state["site"] == label + "-cn" and t_.dim() == 4:   # minus the mean over dim 2 (per MSA row / per outer index)
+                        mu = t_.mean(2, keepdim=True)
+                        t_.copy_((t_ - mu).to(dt).float() + mu)
+                    elif state["site"] == label + "-cl" and t_.dim() == 4:   # minus the mean over dim 1
+                        mu = t_.mean(1, keepdim=True)
+                        t_.copy_((t_ - mu).to(dt).float() + mu)
             return o_gemm(A, B_, Cout, M_, N_, K_, **k)
 
         saved = []
@@ -346,7 +356,9 @@ def main():
             fwd("fp32")   # dry pass: the call sites
             sites = sorted(state["seen"])
             print("[gemm] sites: " + ", ".join(f"{k} x{v}" for k, v in sorted(state["seen"].items())), file=sys.stderr, flush=True)
-            for site in ["ALL"] + sites:
+            if args.gemm_sites:
+                sites = args.gemm_sites.split(",")
+            for site in (["ALL"] if not args.gemm_sites else []) + sites:
                 state["site"] = site
                 out, _ = fwd("fp32")
                 m = metrics(out, ref)
