@@ -48,6 +48,7 @@ class _Runtime:
     # Operand conditioning of the 16-bit modes (csrc/condition.hip; exact algebra): PairUpdateWithMsa's tiled 1-D features and its
     # first convolution see operands with the per-sample constant removed.  RF_CONDITION=0: the plain form (ablation / probes).
     condition = bool(int(__import__("os").environ.get("RF_CONDITION", "1")))
+    condition_values = bool(int(__import__("os").environ.get("RF_CONDITION_V", "1")))   # the attention layers' value path (value_conditioning)
     # SE(3) radial MLPs: last Linear inside the message kernel (csrc/se3.hip: rf_se3_radial_message); RF_SE3_UNFUSED=1 writes the
     # radial outputs with a K = 32 GEMM and reads them back (round-3 path, kept for A/B timing and as the form for unusual shapes)
     se3_fused_radial = not bool(int(__import__("os").environ.get("RF_SE3_UNFUSED", "0")))
@@ -215,7 +216,9 @@ class RFModule(nn.Module):
             v - c = W_v xn - W_v mu            the value block of the projection gets the bias -W_v mu instead of b_v,
             o - c = sum_j a_ij (v_j - c)       the attention kernels run unchanged on the centred values,
             W_o (o - c) + (b_o + W_o c)        the output projection gets the bias b_o + W_o b_v + (W_o W_v) mu.
-        Returns (fp32 [B, n_lead + d_v] bias of the projection whose output columns are [lead..., v], fp32 [B, d_out] output bias);
+        ONE constant serves the whole batch (the identity holds for any c; the constant is dominated by biases, LayerNorm
+        offsets and the mean embedding, which the samples share), so the projections stay single launches over all samples.
+        Returns (fp32 [1, n_lead + d_v] bias of the projection whose output columns are [lead..., v], fp32 [1, d_out] output bias);
         `lead`: the Linear modules in front of v in a fused projection (their biases pass through)."""
         def make():
             wv, wo = to_v.weight.detach().float(), to_out.weight.detach().float()
@@ -229,7 +232,7 @@ class RFModule(nn.Module):
             bc = torch.cat(bl + [torch.zeros(wv.shape[0], device=dev), bo]).contiguous()
             return wc, bc, nl + wv.shape[0]
         wc, bc, npre = self.cached(("vcond", len(lead)), make)
-        r = ops.fold_mean(wc, ops.sample_mean(xn), bc)
+        r = ops.fold_mean(wc, ops.sample_mean(xn.view(1, -1, xn.shape[-1])), bc)
         return r[:, :npre], r[:, npre:]
 
     # kernel-ready views of parameter containers -------------------------------------------------
@@ -604,10 +607,6 @@ class SoftTiedAttentionOverResidues(RFModule):
         H, dh = self.n_heads, self.d_head
         dev = xn.device
         pw = self.poswise_weight
-        if RT.condition and ops.is_h16(T()) and B > 1:
-            # the value conditioning carries a per-sample bias: one sample per projection launch
-            outs = [self.attend(xn[b:b + 1], x_res[b:b + 1], want_att, None, drops) for b in range(B)]
-            return (torch.cat([o_[0] for o_ in outs]) if want_att else None), None
         if (RT.fused_tied and RT.tied_v2 and ops.is_h16(T()) and dh == 32 and Lr in (64, 128, 192, 256) and H <= 16
                 and N % 16 == 0 and N // 16 in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16) and (B * N * Lr) % 256 == 0 and B * N * Lr >= 16384
                 and (6 if Lr >= 256 else 8) * (4096 + Lr * 64) + 1024 + N * 256 <= 160 * 1024):
@@ -638,7 +637,7 @@ class SoftTiedAttentionOverResidues(RFModule):
             ops.poswise(q0, D, qkp, 3 * D, 2 * D, dh, dh, None, qkp, 3 * D, 0, dh, B, N, Lr, H, pw.scale, self.scale)
         # v transposed: v_t[b,n,(h,d),l]
         bv, bo = _f(self.to_v.bias), _f(self.to_out.bias)
-        if RT.condition and ops.is_h16(T()) and B == 1:
+        if RT.condition and RT.condition_values and ops.is_h16(T()):
             bv, bo = (t_[0] for t_ in self.value_conditioning(xn, self.to_v, self.to_out))
         v_t = torch.empty(B, N, D, Lr, device=dev, dtype=T())
         ops.gemm(self.wt("v", self.to_v), xn, v_t, D, Lr, D, batch=(B * N, 1, 1), b_bs=(Lr * D, 0, 0),
@@ -690,7 +689,7 @@ class SoftTiedAttentionOverResidues(RFModule):
         # ... when the projection runs on the kernel whose epilogue knows the row-group scale (d_msa = 288: N = 864 does not)
         fold = RT.tied_fold_w and dh % 16 == 0 and ops.gemm_takes_row_scale(B * N * Lr, 3 * D, D)
         bqkv, bo = self.bcat("qkv", lins), _f(self.to_out.bias)
-        if RT.condition and B == 1:   # (attend() hands this path one sample at a time when the conditioning is on)
+        if RT.condition and RT.condition_values:
             bqkv, bo = (t_[0] for t_ in self.value_conditioning(xn, self.to_v, self.to_out, lead=(self.to_q, self.to_k)))
         ops.gemm(xn, self.wcat("qkv", lins), qkv, B * N * Lr, 3 * D, D, bias=bqkv,
                  c_row=(Lr, G * Lr * dh, dh), c_col=(dh, Lr * dh),
@@ -730,7 +729,7 @@ class SoftTiedAttentionOverResidues(RFModule):
         ops.tied_logits(qk[:, :, 0:H], qk[:, :, H:], att, att_sym)
         # v transposed: v_t[b,n,(h,d),l];  out[b,n,i,(h,d)] = sum_j att[b,h,i,j] v[b,n,h,j,d]   (rf.py:257-258)
         bv, bo = _f(self.to_v.bias), _f(self.to_out.bias)
-        if RT.condition and B == 1:
+        if RT.condition and RT.condition_values:
             bv, bo = (t_[0] for t_ in self.value_conditioning(xn, self.to_v, self.to_out))
         v_t = torch.empty(B, N, D, Lr, device=dev, dtype=T())
         ops.gemm(self.wt("v", self.to_v), xn, v_t, D, Lr, D, batch=(B * N, 1, 1), b_bs=(Lr * D, 0, 0),
@@ -823,11 +822,7 @@ class PerformerSelfAttention(RFModule):
         if seq_group is not None and not gen:
             raise NotImplementedError("sequence-sharded attention is built for the generalized (ReLU) feature map of the pair "
                                       "track only: the softmax feature map needs the global key maximum first")
-        cond = RT.condition and self.condition_v and ops.is_h16(T()) and seq_group is None
-        if cond and B > 1:   # per-sample bias: one sample per launch
-            for b in range(B):
-                self.attend(xn[b:b + 1], x_res[b:b + 1], axis, None, None, drops)
-            return None
+        cond = RT.condition and RT.condition_values and self.condition_v and ops.is_h16(T()) and seq_group is None
         bqkv, bv, bo = None, None, _f(self.to_out.bias)
         if cond:
             bqkv, bo = (t_[0] for t_ in self.value_conditioning(xn, self.to_v, self.to_out, lead=(self.to_q, self.to_k)))

@@ -426,7 +426,7 @@ def channel_mean(x, row_group=None, rows_global=None):
     return mean
 
 
-def sample_mean(x, nsample=2048):
+def sample_mean(x, nsample=512):
     """fp32 [B, C] estimate of the per-channel mean of x [B, ..., C] (fp32 / 16-bit, contiguous) from nsample evenly spaced rows."""
     B, Cc = x.shape[0], x.shape[-1]
     _need_cuda(x)

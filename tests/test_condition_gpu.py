@@ -213,7 +213,9 @@ def test_encoder_layer_value_conditioning(kind, B, N, L, mode):
     D = 384 if (N, L) == (128, 256) else 96
     lay = R.EncoderLayer(d_msa=D, d_ff=2 * D, n_heads=D // 32, p_dropout=0.0, tied=(kind == "tied"), performer=(kind == "performer")).to(DEV)
     _offset_biases(lay, 11)
-    x = rn(B, N, L, D) + 6.0 * rn(B, 1, 1, D, seed=1)
+    # the constant is shared by the samples of a batch (biases, LayerNorm offsets, the mean embedding) up to a small per-sample
+    # part: ONE conditioning constant serves the whole batch (RFModule.value_conditioning)
+    x = rn(B, N, L, D) + 6.0 * rn(1, 1, 1, D, seed=1) + 0.5 * rn(B, 1, 1, D, seed=2)
 
     def update():
         xn = M.ln(lay.ln, x)
