@@ -1275,7 +1275,8 @@ class PairUpdateWithMsa(RFModule):
             x = torch.empty(B, Lr, Lr, Dp, device=dev, dtype=F32)
             for b in range(B):
                 ops.linear(feat[b], self.wt("f", self.resnet[0], kpad=Kf), bias_b[b], out=x[b])
-            cx = ops.channel_mean(x)
+            cx = ops.sample_mean(x)   # an estimate serves: both identities hold for ANY constant (a row-sharded picture needs the
+            #                           same constant on every rank: run_rows all-reduces the exact mean)
             y = conv3x3(self, "c1", blk[1], ops.center_apply(x, cx, out_dtype=T()), 1)
             ops.conv3x3_border_fix(y, self._conv_taps(blk[1], cx), 1)
         else:
