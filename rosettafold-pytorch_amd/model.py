@@ -1192,7 +1192,7 @@ class PairUpdateWithMsa(RFModule):
                         (h * P * Np, P * Np, Np, 1), (B, h, P, Np), x_off=r0 * P * Np)
         coevol = self.outer_product_mean.run_rows(xr, yt, Np)  # fp32 [B,h,L,Dp]
         ln(self.ln_coevol_feat, coevol, out=feat, out_ld=Kf, out_off=0)
-        cond = RT.condition and ops.is_h16(T())
+        cond = RT.condition and ops.is_h16(T()) and Dp % 4 == 0   # (rf_center_apply moves 16-byte chunks of a pixel)
         bias = _f(self.resnet[0].bias)
         if cond:   # (the mean over ALL positions: msa is replicated, every rank folds the same constant)
             bias_b = self._center_1d(msa1d, bias)
@@ -1264,7 +1264,7 @@ class PairUpdateWithMsa(RFModule):
             ln(self.ln_coevol_feat, coevol, out=feat, out_ld=Kf, out_off=0)
         H = att.shape[-1]
         blk = self.resnet[1].fn
-        cond = RT.condition and ops.is_h16(T())
+        cond = RT.condition and ops.is_h16(T()) and Dp % 4 == 0   # (rf_center_apply moves 16-byte chunks of a pixel)
         bias = _f(self.resnet[0].bias)
         if cond:
             bias_b = self._center_1d(msa1d, bias)   # msa1d -= its mean over the positions; [B, Dp] bias that carries W * mean
@@ -1792,7 +1792,7 @@ class PredictionHead(RFModule):
         # picture (tools/precision_probe.py: the first InstanceNorm amplifies a white input error 19x), so x is rounded to 16
         # bits AFTER removing it -- and so is the projection's own operand LayerNorm(pair) (the other 6e-3 of the fp16 mode's
         # logits gap): W (t - mean t) is the projection minus ITS mean over the picture, bias and all.
-        cond = RT.head_center and ops.is_h16(T())
+        cond = RT.head_center and ops.is_h16(T()) and Cc % 4 == 0 and self.proj[1].weight.shape[0] % 4 == 0
         if cond and not self.training:
             t = ln(self.proj[0], pair, out_dtype=F32)
             x = ops.linear(ops.center_apply(t, ops.channel_mean(t, **kwc), out_dtype=T()), self.wt("p", self.proj[1]), None, out_dtype=F32)
